@@ -1,0 +1,148 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X (gfx950) path-tracing module, librt_hip.so.
+ *
+ * novadinn/ray-tracer has no plugin or FFI interface: its compute shader is reached
+ * through Vulkan calls written inline in main().  Each entry point below stands
+ * exactly where one group of those calls stands, takes the same bytes the
+ * reference hands to Vulkan (rt_contract.h), and is cited against the call site it
+ * replaces.  Plain pointers and sizes only; every call returns 0 on success or a
+ * negative rt_status and never aborts; rt_last_error() gives the text for the
+ * calling thread.  A context is used from one host thread at a time.  Inputs are
+ * copied during the call (the reference frees its staging buffer right after the
+ * upload, src/vulkan_buffer.cpp:66-89); outputs are copied into caller memory.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt_contract.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,   /* bad argument */
+  RT_ERR_DEVICE = -2,    /* a HIP call failed */
+  RT_ERR_STATE = -3,     /* call order: e.g. render before set_params/set_spheres */
+  RT_ERR_NOMEM = -4
+} rt_status;
+
+/* kernel organisation for one frame batch */
+typedef enum rt_mode {
+  RT_MODE_MEGAKERNEL = 0, /* one launch, one lane per pixel, paths regenerated in-lane */
+  RT_MODE_WAVEFRONT = 1,  /* raygen / extend / shade stages over compacted queues */
+  RT_MODE_MEGAKERNEL_NESTED = 2 /* the shader's own loop nest, kept as the structural baseline */
+} rt_mode;
+
+enum {
+  /* sin/cos/log/pow from fixed fp32 polynomial kernels instead of the hardware
+   * approximations: every output then equals the CPU restatement bit for bit */
+  RT_FLAG_STRICT_MATH = 1u << 0,
+  /* accumulate the per-frame linear mean instead of the gamma-encoded colour */
+  RT_FLAG_ACCUM_LINEAR = 1u << 1,
+  /* closest-hit search: brute force over all spheres (the shader's loop) even for
+   * large scenes; default is the LBVH once the scene has more than 16 spheres */
+  RT_FLAG_FORCE_BRUTE = 1u << 2,
+  RT_FLAG_FORCE_BVH = 1u << 3
+};
+
+typedef struct rt_config {
+  uint32_t struct_size;   /* sizeof(rt_config) */
+  int32_t device;         /* HIP device ordinal */
+  uint32_t width, height; /* image size in pixels */
+  uint32_t mode;          /* rt_mode */
+  uint32_t flags;         /* RT_FLAG_* */
+  void *stream;           /* hipStream_t to launch on, or NULL for the null stream */
+  void *accum_buffer;     /* optional caller-owned device buffer, width*height*16 bytes,
+                             used instead of an internal one (lets the caller hand the
+                             accumulation image to a collective without a copy) */
+} rt_config;
+
+typedef struct rt_stats {
+  uint64_t rays;            /* path segments traced since rt_clear (one per closest-hit search) */
+  uint64_t frames;          /* frames rendered since rt_clear */
+  float last_render_ms;     /* device time of the last rt_render, HIP events on the stream */
+  float total_render_ms;    /* sum of the above since rt_clear */
+  uint32_t last_launches;   /* kernel launches issued by the last rt_render */
+  uint32_t bvh_nodes;       /* internal nodes of the current LBVH, 0 when brute force */
+  float last_build_ms;      /* device time of the last LBVH build */
+  uint32_t reserved;
+} rt_stats;
+
+/* Replaces createTexture(RGBA8_UNORM, W, H, STORAGE) + zero fill, main.cpp:393-448,
+ * and createBuffer(UBO)/createBuffer(SSBO), main.cpp:487-495,540-548: allocates the
+ * 8-bit image (zeroed), the float accumulation image and the parameter block. */
+int rt_create(const rt_config *cfg, rt_ctx **out_ctx);
+
+/* Replaces destroyTexture/destroyBuffer, main.cpp:1044-1051. */
+int rt_destroy(rt_ctx *ctx);
+
+/* Replaces loadBufferData(&compute_ubo_buffer, ...), main.cpp:703
+ * (vulkan_buffer.cpp:57-64): takes the shader's 272-byte std140 block as is.
+ * ubo->frame.x is ignored; rt_render supplies the frame index. */
+int rt_set_params(rt_ctx *ctx, const void *ubo272);
+
+/* Replaces loadBufferDataStaging(&compute_ssbo, ...), main.cpp:549-554: count records
+ * of 64 bytes (rt_sphere).  Rebuilds the acceleration structure when one is used. */
+int rt_set_spheres(rt_ctx *ctx, const void *spheres64, uint32_t count);
+
+/* Replaces bind pipeline + descriptor sets + vkCmdDispatch(W/16,H/16,1) + submit,
+ * main.cpp:819-868, for n_frames dispatches with ubo.frame.x = first_frame,
+ * first_frame + frame_stride, ...  (main.cpp:1028 increments it by one per
+ * dispatch).  Every pixel is shaded (ceil-div grid with a bounds guard).
+ * Asynchronous: returns after enqueueing on the context's stream. */
+int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride);
+
+/* Replaces vkWaitForFences on the compute fence, main.cpp:872-874. */
+int rt_sync(rt_ctx *ctx);
+
+/* The reference restarts accumulation by resetting ubo.frame.x to 0 on any edit,
+ * main.cpp:1028-1031, which makes the next dispatch overwrite the image; this
+ * zeroes image, accumulation buffer, id map and statistics explicitly. */
+int rt_clear(rt_ctx *ctx);
+
+/* Replaces the blit's read of the result image, main.cpp:951-957: the 8-bit image as
+ * the shader's own progressive blend leaves it (width*height*4 bytes, row 0 first;
+ * the reference shows it bottom-up, main.cpp:934-940). */
+int rt_read_rgba8(rt_ctx *ctx, void *host, size_t bytes);
+
+/* No counterpart in the reference (it accumulates only in the 8-bit image): the
+ * float accumulation image, width*height float4 = (sum over frames of the frame
+ * colour, number of frames). */
+int rt_read_accum_f32(rt_ctx *ctx, void *host, size_t bytes);
+
+/* No counterpart in the reference: per pixel, the index of the sphere hit by the
+ * first segment of sample 0 of the last frame rendered, -1 for a miss (int32). */
+int rt_read_primary_ids(rt_ctx *ctx, void *host, size_t bytes);
+
+/* Rewrites the 8-bit image from the float accumulation image (mean over frames,
+ * gamma applied if the sums are linear, then the rgba8 store conversion).  Used
+ * after a multi-GPU sum, where no single device ran the progressive blend. */
+int rt_resolve(rt_ctx *ctx);
+
+/* Device address and size of the accumulation image, for collectives. */
+int rt_accum_device_ptr(rt_ctx *ctx, void **out_dptr, size_t *out_bytes);
+
+/* Waits for the stream, then reports counters. */
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+/* Test hook, no counterpart in the reference: evaluates one device math routine
+ * elementwise on host arrays so tests can compare it bit for bit with the CPU.
+ * op: 0 sqrt(a) 1 a/b 2 sin(a) 3 cos(a) 4 log(a) 5 log2(a) 6 exp2(a) 7 pow(a,b)
+ * (2..7 are the strict-math polynomial kernels), 8..13 the fast counterparts of
+ * 2..7 (hardware approximations). */
+int rt_debug_eval(int device, int op, const float *a, const float *b, float *out, size_t n);
+
+const char *rt_last_error(void);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

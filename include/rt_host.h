@@ -1,0 +1,61 @@
+/*
+ * rt_host.h -- host-side half of the drop-in contract: the reference's camera
+ * (src/camera.h, src/camera.cpp) and its default scene and render settings
+ * (src/main.cpp), restated without glm so that a caller can fill the 272-byte
+ * uniform block and the 64-byte sphere records exactly as the reference's main()
+ * does.  Exported from librt_hip.so next to the device entry points (rt_hip.h).
+ *
+ * Matrices are column-major float[16].
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_contract.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Camera's in-class initialisers, camera.h:7-13 */
+void rt_camera_init(rt_camera *cam);
+/* createCamera, camera.cpp:5-13 */
+void rt_camera_create(float start_fov, float start_aspect_ratio, float start_near,
+                      float start_far, rt_camera *out_camera);
+/* cameraRotate, camera.cpp:15-19 (delta = mouse delta * 0.01, main.cpp:682-686) */
+void rt_camera_rotate(rt_camera *cam, float delta_x, float delta_y);
+/* cameraGetProjectionMatrix, camera.cpp:21-25: left-handed, depth -1..1
+ * (CMakeLists.txt:28-30); also refreshes cam->aspect_ratio like the reference */
+void rt_camera_projection_matrix(rt_camera *cam, float out16[16]);
+/* cameraGetViewMatrix, camera.cpp:27-34 */
+void rt_camera_view_matrix(const rt_camera *cam, float out16[16]);
+/* cameraGetOrientation, camera.cpp:48-50; out = (w, x, y, z) */
+void rt_camera_orientation(const rt_camera *cam, float out_wxyz[4]);
+/* cameraGetUp / Right / Forward, camera.cpp:36-46 */
+void rt_camera_up(const rt_camera *cam, float out3[3]);
+void rt_camera_right(const rt_camera *cam, float out3[3]);
+void rt_camera_forward(const rt_camera *cam, float out3[3]);
+/* cameraGetPanSpeed / RotationSpeed / ZoomSpeed, camera.cpp:52-71 */
+void rt_camera_pan_speed(const rt_camera *cam, float out2[2]);
+float rt_camera_rotation_speed(const rt_camera *cam);
+float rt_camera_zoom_speed(const rt_camera *cam);
+
+/* The uniform block as main() fills it: render settings main.cpp:626-636, camera
+ * part main.cpp:697-701.  cam == NULL uses createCamera(90, 1, 0.01, 10000), i.e.
+ * main.cpp:624 where 800/608 is an unsigned division. */
+void rt_default_ubo(rt_camera *cam, rt_ubo *out);
+/* Only the camera-dependent fields (view, projection, viewportSize, cameraPosition),
+ * as the frame loop rewrites them every frame, main.cpp:697-701. */
+void rt_ubo_set_camera(rt_camera *cam, rt_ubo *ubo);
+/* The three spheres of main.cpp:517-538; returns 3. */
+uint32_t rt_default_scene(rt_sphere out3[3]);
+
+/* Writes a binary PPM (P6) of an rgba8 image; flip_y != 0 writes the last buffer row
+ * first, which is how the reference's window shows the image (negative viewport
+ * height, main.cpp:934-940).  Returns 0, or -1 with errno set. */
+int rt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
+                 int flip_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+/*
+ * rt_oracle.h -- CPU oracle for the per-pixel path-tracing loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (ray_tracer_amd/, include/)
+ * may include, link or call this; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference (novadinn/ray-tracer) ships no tests, golden
+ * vectors or fixtures for this path, and its shader cannot be compiled or run in
+ * this image (no glslang, no Vulkan loader, no lavapipe).  This file is a
+ * restatement of assets/shaders/ray_tracing.comp and src/camera.cpp written from
+ * the source text; it is pinned only by closed-form known answers that follow
+ * from that text (PCG streams, primary-hit census, centre-pixel distance).
+ *
+ * Numerics policy.  GLSL leaves FMA contraction and the precision of
+ * inverse/normalize/sin/cos/log/pow to the driver, so the oracle fixes ONE valid
+ * instance of the shader and documents it:
+ *   - add/mul/fma exactly as written here (compiled with -ffp-contract=off, every
+ *     fused operation spelled fmaf);
+ *   - sqrt and division IEEE-754 correctly rounded;
+ *   - RTO_MATH_PORTABLE: sin/cos/log/log2/exp2 are fixed fp32 polynomial kernels
+ *     (this file), reproducible bit for bit on any IEEE machine, GPU included;
+ *   - RTO_MATH_LIBM: the same program with the host libm's sinf/cosf/logf/powf,
+ *     used to show the polynomial kernels do not bias the image.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RTO_MATH_PORTABLE = 0, RTO_MATH_LIBM = 1 };
+enum { RTO_ACCUM_GAMMA = 0, RTO_ACCUM_LINEAR = 1 };
+
+/* --- RNG (ray_tracing.comp:112-119) --- */
+uint32_t rto_next_random(uint32_t *state);
+float rto_random_value(uint32_t *state);
+
+/* --- portable transcendental kernels (exported so tests can bound their error) --- */
+float rto_pm_sin(float x);
+float rto_pm_cos(float x);
+float rto_pm_log(float x);
+float rto_pm_log2(float x);
+float rto_pm_exp2(float x);
+float rto_pm_pow(float x, float y);
+
+/* --- camera.cpp:5-50 restated without glm; matrices are column-major float[16] --- */
+typedef struct rto_camera {
+  float fov, near_, far_;
+  float pitch, yaw;
+  float aspect_ratio;
+  float distance;
+  float viewport_width, viewport_height;
+} rto_camera;
+
+void rto_camera_default(rto_camera *cam);                       /* camera.h:7-13 */
+void rto_camera_create(float fov, float aspect, float near_, float far_,
+                       rto_camera *cam);                        /* camera.cpp:5-13 */
+void rto_camera_rotate(rto_camera *cam, float dx, float dy);    /* camera.cpp:15-19 */
+void rto_camera_projection(rto_camera *cam, float out16[16]);   /* camera.cpp:21-25 */
+void rto_camera_view(const rto_camera *cam, float out16[16]);   /* camera.cpp:27-34 */
+void rto_camera_orientation(const rto_camera *cam, float out_wxyz[4]); /* camera.cpp:48-50 */
+void rto_camera_up(const rto_camera *cam, float out3[3]);       /* camera.cpp:36-38 */
+void rto_camera_right(const rto_camera *cam, float out3[3]);    /* camera.cpp:40-42 */
+void rto_camera_forward(const rto_camera *cam, float out3[3]);  /* camera.cpp:44-46 */
+
+/* general 4x4 inverse (GLSL inverse(), ray_tracing.comp:230,233), column-major */
+void rto_mat4_inverse(const float m[16], float out[16]);
+
+/* default UBO (main.cpp:626-636,697-701) and default scene (main.cpp:517-538) */
+void rto_default_ubo(const rto_camera *cam_or_null, void *ubo272);
+uint32_t rto_default_spheres(void *spheres64x3);
+
+/*
+ * Render frames first_frame, first_frame+stride, ... (n_frames of them) of a
+ * W x H image exactly as ray_tracing.comp:74-110 would, one invocation per pixel
+ * (every pixel, i.e. a ceil-div dispatch with a bounds guard).
+ *
+ *   ubo272     the shader's 272-byte std140 uniform block; ubo.frame.x is
+ *              overwritten per frame with the frame index
+ *   spheres64  n_spheres records of 64 bytes (std140 Sphere)
+ *   accum      optional W*H*4 floats, ADDED to: rgb += per-frame colour (gamma
+ *              encoded for RTO_ACCUM_GAMMA, linear mean for RTO_ACCUM_LINEAR),
+ *              a += 1 per frame
+ *   rgba8      optional W*H*4 bytes, read-modify-written with the shader's own
+ *              progressive blend in an 8-bit UNORM image (ray_tracing.comp:103-109)
+ *   ids        optional W*H int32: index of the sphere hit by the first path
+ *              segment of sample 0 of the last frame rendered, -1 on a miss
+ *   rays       optional: number of calculateRayCollision calls is ADDED to *rays
+ *   threads    host threads (rows are handed out dynamically); <=0 means 1
+ * Returns 0, or -1 on bad arguments.
+ */
+int rto_render(const void *ubo272, const void *spheres64, uint32_t n_spheres,
+               uint32_t width, uint32_t height, uint32_t first_frame,
+               uint32_t n_frames, uint32_t frame_stride, int math_mode,
+               int accum_mode, float *accum, uint8_t *rgba8, int32_t *ids,
+               uint64_t *rays, int threads);
+
+/* accum (rgb sum, a = frame count) -> rgba8 with the image-store conversion */
+void rto_resolve_rgba8(const float *accum, uint32_t n_pixels, int accum_mode,
+                       uint8_t *rgba8);
+
+/* float -> UNORM8 as imageStore on an rgba8 image does it */
+uint8_t rto_unorm8(float v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,407 @@
+// C ABI of librt_hip.so (include/rt_hip.h): context management, uploads, launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_hostmath.h"
+#include "rt_kernels.h"
+#include "rt_lbvh.h"
+#include "rt_wavefront.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define RT_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RT_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+// trip count of "for (int i = 0; i < limit; i++)" with a float limit
+int trip_count(float limit) {
+  if (!(limit > 0.0f)) return 0;
+  float c = std::ceil(limit);
+  if (c > 16777216.0f) c = 16777216.0f;
+  return (int)c;
+}
+
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t width = 0, height = 0, mode = 0, flags = 0;
+  size_t n_pixels = 0;
+
+  rt::Params P{};
+  bool have_params = false;
+
+  float4 *d_geom = nullptr;      // centre.xyz, r*r
+  float4 *d_material = nullptr;  // 3 per sphere
+  uint32_t n_spheres = 0;
+  bool have_scene = false;
+  std::vector<float> h_spheres;  // the 64-byte records as uploaded (for rebuilds)
+
+  rt::Lbvh bvh;                  // device LBVH + build workspace
+  bool use_bvh = false;
+
+  rt::WavefrontState wf;         // queues of the wavefront pipeline
+
+  float4 *d_accum = nullptr;
+  bool own_accum = false;
+  uchar4 *d_rgba8 = nullptr;
+  int32_t *d_ids = nullptr;
+  unsigned long long *d_rays = nullptr;
+
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  bool timing_pending = false;
+  uint64_t frames = 0;
+  float last_ms = 0.f, total_ms = 0.f;
+  uint32_t last_launches = 0;
+};
+
+namespace {
+
+int collect_timing(rt_ctx *c) {
+  if (c->timing_pending) {
+    float ms = 0.f;
+    RT_HIP(hipEventSynchronize(c->ev_end));
+    RT_HIP(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+    c->last_ms = ms;
+    c->total_ms += ms;
+    c->timing_pending = false;
+  }
+  return RT_OK;
+}
+
+rt::Scene scene_view(const rt_ctx *c) {
+  rt::Scene S{};
+  S.geom = c->d_geom;
+  S.material = c->d_material;
+  S.n_spheres = c->n_spheres;
+  if (c->use_bvh) {
+    S.nodes = c->bvh.nodes;
+    S.sorted_prim = c->bvh.sorted_prim;
+    S.sorted_geom = c->bvh.sorted_geom;
+  }
+  return S;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+const char *rt_version(void) { return "rt_hip 0.1 (gfx950)"; }
+
+int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
+  if (!cfg || !out_ctx) return fail(RT_ERR_INVALID, "rt_create: null argument");
+  if (cfg->struct_size != sizeof(rt_config))
+    return fail(RT_ERR_INVALID, "rt_create: struct_size %u, expected %zu", cfg->struct_size,
+                sizeof(rt_config));
+  if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65536u || cfg->height > 65536u)
+    return fail(RT_ERR_INVALID, "rt_create: bad image size %ux%u", cfg->width, cfg->height);
+  if (cfg->mode > RT_MODE_MEGAKERNEL_NESTED)
+    return fail(RT_ERR_INVALID, "rt_create: unknown mode %u", cfg->mode);
+  if ((cfg->flags & RT_FLAG_FORCE_BRUTE) && (cfg->flags & RT_FLAG_FORCE_BVH))
+    return fail(RT_ERR_INVALID, "rt_create: FORCE_BRUTE and FORCE_BVH are exclusive");
+  int n_dev = 0;
+  RT_HIP(hipGetDeviceCount(&n_dev));
+  if (cfg->device < 0 || cfg->device >= n_dev)
+    return fail(RT_ERR_INVALID, "rt_create: device %d of %d", cfg->device, n_dev);
+  RT_HIP(hipSetDevice(cfg->device));
+
+  rt_ctx *c = new (std::nothrow) rt_ctx();
+  if (!c) return fail(RT_ERR_NOMEM, "rt_create: out of host memory");
+  c->device = cfg->device;
+  c->stream = (hipStream_t)cfg->stream;
+  c->width = cfg->width;
+  c->height = cfg->height;
+  c->mode = cfg->mode;
+  c->flags = cfg->flags;
+  c->n_pixels = (size_t)cfg->width * cfg->height;
+
+  auto bail = [&](hipError_t e, const char *what) {
+    int rc = fail(RT_ERR_DEVICE, "rt_create: %s: %s", what, hipGetErrorString(e));
+    rt_destroy(c);
+    return rc;
+  };
+  hipError_t e;
+  if (cfg->accum_buffer) {
+    c->d_accum = (float4 *)cfg->accum_buffer;
+  } else {
+    if ((e = hipMalloc(&c->d_accum, c->n_pixels * sizeof(float4))) != hipSuccess)
+      return bail(e, "hipMalloc(accum)");
+    c->own_accum = true;
+  }
+  if ((e = hipMalloc(&c->d_rgba8, c->n_pixels * sizeof(uchar4))) != hipSuccess)
+    return bail(e, "hipMalloc(rgba8)");
+  if ((e = hipMalloc(&c->d_ids, c->n_pixels * sizeof(int32_t))) != hipSuccess)
+    return bail(e, "hipMalloc(ids)");
+  if ((e = hipMalloc(&c->d_rays, 256)) != hipSuccess) return bail(e, "hipMalloc(rays)");
+  if ((e = hipEventCreate(&c->ev_begin)) != hipSuccess) return bail(e, "hipEventCreate");
+  if ((e = hipEventCreate(&c->ev_end)) != hipSuccess) return bail(e, "hipEventCreate");
+  int rc = rt_clear(c);
+  if (rc != RT_OK) {
+    rt_destroy(c);
+    return rc;
+  }
+  *out_ctx = c;
+  return RT_OK;
+}
+
+int rt_destroy(rt_ctx *c) {
+  if (!c) return RT_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->own_accum && c->d_accum) hipFree(c->d_accum);
+  if (c->d_rgba8) hipFree(c->d_rgba8);
+  if (c->d_ids) hipFree(c->d_ids);
+  if (c->d_rays) hipFree(c->d_rays);
+  if (c->d_geom) hipFree(c->d_geom);
+  if (c->d_material) hipFree(c->d_material);
+  c->bvh.release();
+  c->wf.release();
+  if (c->ev_begin) hipEventDestroy(c->ev_begin);
+  if (c->ev_end) hipEventDestroy(c->ev_end);
+  delete c;
+  return RT_OK;
+}
+
+int rt_clear(rt_ctx *c) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_clear: null context");
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipMemsetAsync(c->d_accum, 0, c->n_pixels * sizeof(float4), c->stream));
+  RT_HIP(hipMemsetAsync(c->d_rgba8, 0, c->n_pixels * sizeof(uchar4), c->stream));
+  RT_HIP(hipMemsetAsync(c->d_ids, 0xff, c->n_pixels * sizeof(int32_t), c->stream));
+  RT_HIP(hipMemsetAsync(c->d_rays, 0, 256, c->stream));
+  c->frames = 0;
+  c->last_ms = c->total_ms = 0.f;
+  c->last_launches = 0;
+  c->timing_pending = false;
+  return RT_OK;
+}
+
+int rt_set_params(rt_ctx *c, const void *ubo272) {
+  if (!c || !ubo272) return fail(RT_ERR_INVALID, "rt_set_params: null argument");
+  rt_ubo u;
+  std::memcpy(&u, ubo272, sizeof u);
+  rt::Params &P = c->P;
+  rt::mat4_inverse(u.view, P.inv_view);
+  rt::mat4_inverse(u.projection, P.inv_proj);
+  P.viewport_w = u.viewport_size[0];
+  P.viewport_h = u.viewport_size[1];
+  P.cam_x = u.camera_position[0];
+  P.cam_y = u.camera_position[1];
+  P.cam_z = u.camera_position[2];
+  P.spp_f = u.render_settings[0];
+  P.n_spp = trip_count(u.render_settings[0]);
+  P.n_bounce = trip_count(u.render_settings[1]);
+  for (int k = 0; k < 3; ++k) {
+    P.ground[k] = u.ground_colour[k];
+    P.horizon[k] = u.sky_colour_horizon[k];
+    P.zenith[k] = u.sky_colour_zenith[k];
+    P.sun[k] = u.sun_position[k];
+  }
+  P.sun_focus = u.sun_focus;
+  P.sun_intensity = u.sun_intensity;
+  P.defocus = u.defocus_strength;
+  P.diverge = u.diverge_strength;
+  P.width = c->width;
+  P.height = c->height;
+  P.fwidth = (float)c->width;
+  P.fheight = (float)c->height;
+  P.defocus_over_w = P.defocus / P.fwidth;
+  P.diverge_over_w = P.diverge / P.fwidth;
+  P.rcp_w = 1.0f / P.fwidth;
+  P.rcp_h = 1.0f / P.fheight;
+  c->have_params = true;
+  return RT_OK;
+}
+
+int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_set_spheres: null context");
+  if (count && !spheres64) return fail(RT_ERR_INVALID, "rt_set_spheres: null data");
+  if (count > (1u << 26)) return fail(RT_ERR_INVALID, "rt_set_spheres: %u spheres", count);
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipStreamSynchronize(c->stream));  // previous launches may still read the old scene
+  if (c->d_geom) RT_HIP(hipFree(c->d_geom));
+  if (c->d_material) RT_HIP(hipFree(c->d_material));
+  c->d_geom = nullptr;
+  c->d_material = nullptr;
+  c->n_spheres = count;
+  c->use_bvh = false;
+  const size_t alloc_n = count ? count : 1;
+  RT_HIP(hipMalloc(&c->d_geom, alloc_n * sizeof(float4)));
+  RT_HIP(hipMalloc(&c->d_material, alloc_n * 3 * sizeof(float4)));
+  c->h_spheres.assign((const float *)spheres64, (const float *)spheres64 + (size_t)count * 16);
+  if (count) {
+    // repack the 64-byte records: geometry (centre, r*r) apart from the material,
+    // so the closest-hit loop streams 16 bytes per sphere instead of 64
+    std::vector<float> geom((size_t)count * 4), mat((size_t)count * 12);
+    const float *s = c->h_spheres.data();
+    for (uint32_t i = 0; i < count; ++i) {
+      const float *r = s + (size_t)i * 16;
+      geom[4 * (size_t)i + 0] = r[0];
+      geom[4 * (size_t)i + 1] = r[1];
+      geom[4 * (size_t)i + 2] = r[2];
+      geom[4 * (size_t)i + 3] = r[3] * r[3];
+      std::memcpy(&mat[12 * (size_t)i], r + 4, 48);
+    }
+    RT_HIP(hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(c->d_material, mat.data(), mat.size() * sizeof(float),
+                     hipMemcpyHostToDevice));
+  }
+  bool want_bvh = (c->flags & RT_FLAG_FORCE_BVH) != 0 ||
+                  (!(c->flags & RT_FLAG_FORCE_BRUTE) && count > 16u);
+  if (want_bvh && count >= 1) {
+    std::string err;
+    int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), count, c->stream, &err);
+    if (rc != RT_OK) return fail(rc, "rt_set_spheres: LBVH build: %s", err.c_str());
+    c->use_bvh = true;
+  }
+  c->have_scene = true;
+  return RT_OK;
+}
+
+int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_render: null context");
+  if (!c->have_params) return fail(RT_ERR_STATE, "rt_render: rt_set_params has not been called");
+  if (!c->have_scene) return fail(RT_ERR_STATE, "rt_render: rt_set_spheres has not been called");
+  if (n_frames == 0) return RT_OK;
+  if (frame_stride == 0) return fail(RT_ERR_INVALID, "rt_render: frame_stride must be >= 1");
+  RT_HIP(hipSetDevice(c->device));
+  if (collect_timing(c) != RT_OK) return RT_ERR_DEVICE;
+
+  rt::FrameSeq F{first_frame, n_frames, frame_stride};
+  rt::Outputs O{};
+  O.accum = c->d_accum;
+  O.rgba8 = c->d_rgba8;
+  O.ids = c->d_ids;
+  O.rays = c->d_rays;
+  O.linear_accum = (c->flags & RT_FLAG_ACCUM_LINEAR) ? 1u : 0u;
+  const rt::Scene S = scene_view(c);
+  const bool strict = (c->flags & RT_FLAG_STRICT_MATH) != 0;
+  const bool degenerate = c->P.n_spp < 1 || c->P.n_bounce < 1;
+
+  RT_HIP(hipEventRecord(c->ev_begin, c->stream));
+  uint32_t launches = 0;
+  if (c->mode == RT_MODE_WAVEFRONT && !degenerate) {
+    std::string err;
+    int rc = c->wf.render(strict, c->use_bvh, c->P, S, F, O, c->stream, &launches, &err);
+    if (rc != RT_OK) return fail(rc, "rt_render: wavefront: %s", err.c_str());
+  } else {
+    const bool nested = degenerate || c->mode == RT_MODE_MEGAKERNEL_NESTED;
+    RT_HIP(rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream));
+    launches = 1;
+  }
+  RT_HIP(hipEventRecord(c->ev_end, c->stream));
+  c->timing_pending = true;
+  c->frames += n_frames;
+  c->last_launches = launches;
+  return RT_OK;
+}
+
+int rt_sync(rt_ctx *c) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_sync: null context");
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+static int read_back(rt_ctx *c, const void *dptr, size_t expect, void *host, size_t bytes,
+                     const char *who) {
+  if (!c || !host) return fail(RT_ERR_INVALID, "%s: null argument", who);
+  if (bytes != expect) return fail(RT_ERR_INVALID, "%s: %zu bytes given, %zu needed", who, bytes, expect);
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+  RT_HIP(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_read_rgba8(rt_ctx *c, void *host, size_t bytes) {
+  return read_back(c, c ? c->d_rgba8 : nullptr, c ? c->n_pixels * 4 : 0, host, bytes, "rt_read_rgba8");
+}
+int rt_read_accum_f32(rt_ctx *c, void *host, size_t bytes) {
+  return read_back(c, c ? c->d_accum : nullptr, c ? c->n_pixels * 16 : 0, host, bytes,
+                   "rt_read_accum_f32");
+}
+int rt_read_primary_ids(rt_ctx *c, void *host, size_t bytes) {
+  return read_back(c, c ? c->d_ids : nullptr, c ? c->n_pixels * 4 : 0, host, bytes,
+                   "rt_read_primary_ids");
+}
+
+int rt_resolve(rt_ctx *c) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_resolve: null context");
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(rt::launch_resolve(c->d_accum, c->d_rgba8, (uint32_t)c->n_pixels,
+                            (c->flags & RT_FLAG_ACCUM_LINEAR) ? 1u : 0u, c->stream));
+  return RT_OK;
+}
+
+int rt_accum_device_ptr(rt_ctx *c, void **out_dptr, size_t *out_bytes) {
+  if (!c || !out_dptr) return fail(RT_ERR_INVALID, "rt_accum_device_ptr: null argument");
+  *out_dptr = c->d_accum;
+  if (out_bytes) *out_bytes = c->n_pixels * sizeof(float4);
+  return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *c, rt_stats *out) {
+  if (!c || !out) return fail(RT_ERR_INVALID, "rt_get_stats: null argument");
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipStreamSynchronize(c->stream));
+  if (collect_timing(c) != RT_OK) return RT_ERR_DEVICE;
+  unsigned long long rays = 0;
+  RT_HIP(hipMemcpy(&rays, c->d_rays, sizeof rays, hipMemcpyDeviceToHost));
+  std::memset(out, 0, sizeof *out);
+  out->rays = rays;
+  out->frames = c->frames;
+  out->last_render_ms = c->last_ms;
+  out->total_render_ms = c->total_ms;
+  out->last_launches = c->last_launches;
+  out->bvh_nodes = c->use_bvh ? c->bvh.n_nodes : 0u;
+  out->last_build_ms = c->bvh.last_build_ms;
+  return RT_OK;
+}
+
+int rt_debug_eval(int device, int op, const float *a, const float *b, float *out, size_t n) {
+  if (!a || !out) return fail(RT_ERR_INVALID, "rt_debug_eval: null argument");
+  if (op < 0 || op > 15) return fail(RT_ERR_INVALID, "rt_debug_eval: unknown op %d", op);
+  if (n == 0) return RT_OK;
+  RT_HIP(hipSetDevice(device));
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  RT_HIP(hipMalloc(&da, n * sizeof(float)));
+  RT_HIP(hipMalloc(&dout, n * sizeof(float)));
+  if (b) RT_HIP(hipMalloc(&db, n * sizeof(float)));
+  RT_HIP(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
+  if (b) RT_HIP(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
+  hipError_t e = rt::launch_debug_eval(op, da, db, dout, n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(da);
+  hipFree(dout);
+  if (db) hipFree(db);
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_debug_eval: %s", hipGetErrorString(e));
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Device-side views of parameters, scene and outputs (plain structs passed by value
+// as kernel arguments, so uniform fields live in scalar registers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// Everything the shader reads from its uniform block (ray_tracing.comp:38-54),
+// with the loop-invariant work hoisted by the host: both matrix inverses
+// (ray_tracing.comp:230,233 recompute them per sample) and integer trip counts.
+struct Params {
+  float inv_view[16];  // column-major
+  float inv_proj[16];
+  float viewport_w, viewport_h;
+  float cam_x, cam_y, cam_z;
+  float spp_f;     // renderSettings.x as stored (the divisor of the mean)
+  int n_spp;       // iterations of "for (i = 0; i < renderSettings.x; i++)"
+  int n_bounce;    // iterations of "for (i = 0; i < renderSettings.y; i++)"
+  float ground[3], horizon[3], zenith[3], sun[3];
+  float sun_focus, sun_intensity;
+  float defocus, diverge;
+  uint32_t width, height;
+  float fwidth, fheight;    // float(imageSize)
+  float defocus_over_w;     // defocus / fwidth   (fast-math jitter scale)
+  float diverge_over_w;     // diverge / fwidth
+  float rcp_w, rcp_h;       // 1 / fwidth, 1 / fheight
+};
+
+// Node of the linear BVH: an internal node stores the bounds of its two children,
+// so one 64-byte fetch decides both.  child < 0 encodes a leaf: ~child is the
+// position in the Morton-sorted primitive order.
+struct BvhNode {
+  float lo0[3];
+  int32_t child0;
+  float hi0[3];
+  int32_t count0;   // primitives under child0 (unused by traversal, kept for stats)
+  float lo1[3];
+  int32_t child1;
+  float hi1[3];
+  int32_t count1;
+};
+
+struct Scene {
+  const float4 *geom;       // per sphere: centre.xyz, radius*radius   (original order)
+  const float4 *material;   // per sphere: colour, emission, specular  (3 x float4)
+  uint32_t n_spheres;
+  // LBVH (null when brute force is used)
+  const BvhNode *nodes;     // n_spheres-1 internal nodes, root = 0
+  const uint32_t *sorted_prim;  // leaf position -> original sphere index
+  const float4 *sorted_geom;    // geom[] permuted into leaf order
+};
+
+struct FrameSeq {
+  uint32_t first, count, stride;
+};
+
+struct Outputs {
+  float4 *accum;            // rgb += frame colour, a += 1, per frame
+  uchar4 *rgba8;            // the shader's own 8-bit progressive image
+  int32_t *ids;             // first-segment hit of sample 0 (last frame wins)
+  unsigned long long *rays; // += closest-hit searches
+  uint32_t linear_accum;    // 1: accumulate the linear mean, 0: the gamma-encoded colour
+};
+
+}  // namespace rt

@@ -1,0 +1,223 @@
+// Host half of the contract (include/rt_host.h): the reference's camera and default
+// scene, restated without glm.  Compiled with -ffp-contract=off; all arithmetic is
+// fp32 like glm's, trigonometry comes from the host libm like glm's std::cos/sin/tan.
+#include "../../include/rt_host.h"
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "rt_hostmath.h"
+
+namespace {
+
+struct Quat {
+  float w, x, y, z;
+};
+
+// glm::quat(vec3 eulerAngles) with angles (-pitch, -yaw, 0): camera.cpp:48-50
+Quat orientation_of(const rt_camera &cam) {
+  const float hx = -cam.pitch * 0.5f, hy = -cam.yaw * 0.5f, hz = 0.0f * 0.5f;
+  const float cx = std::cos(hx), cy = std::cos(hy), cz = std::cos(hz);
+  const float sx = std::sin(hx), sy = std::sin(hy), sz = std::sin(hz);
+  Quat q;
+  q.w = cx * cy * cz + sx * sy * sz;
+  q.x = sx * cy * cz - cx * sy * sz;
+  q.y = cx * sy * cz + sx * cy * sz;
+  q.z = cx * cy * sz - sx * sy * cz;
+  return q;
+}
+
+// glm::rotate(quat, vec3): v + 2 * (w * (qv x v) + qv x (qv x v))
+void rotate_by(const Quat &q, float vx, float vy, float vz, float out[3]) {
+  const float ux = q.y * vz - vy * q.z, uy = q.z * vx - vz * q.x, uz = q.x * vy - vx * q.y;
+  const float wx = q.y * uz - uy * q.z, wy = q.z * ux - uz * q.x, wz = q.x * uy - ux * q.y;
+  out[0] = vx + ((ux * q.w) + wx) * 2.0f;
+  out[1] = vy + ((uy * q.w) + wy) * 2.0f;
+  out[2] = vz + ((uz * q.w) + wz) * 2.0f;
+}
+
+float pan_factor(float extent) {
+  const float v = std::fmin(extent / 1000.0f, 2.4f);
+  return 0.0366f * (v * v) - 0.1778f * v + 0.3021f;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rt_camera_init(rt_camera *cam) {
+  cam->fov = 45.0f;
+  cam->near_plane = 0.1f;
+  cam->far_plane = 1000.0f;
+  cam->pitch = 0.0f;
+  cam->yaw = 0.0f;
+  cam->aspect_ratio = 1.778f;
+  cam->distance = 10.0f;
+  cam->viewport_width = 800.0f;
+  cam->viewport_height = 600.0f;
+}
+
+void rt_camera_create(float start_fov, float start_aspect_ratio, float start_near, float start_far,
+                      rt_camera *out_camera) {
+  rt_camera_init(out_camera);
+  out_camera->fov = start_fov;
+  out_camera->aspect_ratio = start_aspect_ratio;
+  out_camera->near_plane = start_near;
+  out_camera->far_plane = start_far;
+}
+
+void rt_camera_orientation(const rt_camera *cam, float out_wxyz[4]) {
+  const Quat q = orientation_of(*cam);
+  out_wxyz[0] = q.w;
+  out_wxyz[1] = q.x;
+  out_wxyz[2] = q.y;
+  out_wxyz[3] = q.z;
+}
+
+void rt_camera_up(const rt_camera *cam, float out3[3]) {
+  rotate_by(orientation_of(*cam), 0.0f, 1.0f, 0.0f, out3);
+}
+void rt_camera_right(const rt_camera *cam, float out3[3]) {
+  rotate_by(orientation_of(*cam), 1.0f, 0.0f, 0.0f, out3);
+}
+void rt_camera_forward(const rt_camera *cam, float out3[3]) {
+  rotate_by(orientation_of(*cam), 0.0f, 0.0f, 1.0f, out3);
+}
+
+float rt_camera_rotation_speed(const rt_camera *) { return 0.8f; }
+
+float rt_camera_zoom_speed(const rt_camera *cam) {
+  float d = std::fmax(cam->distance * 0.2f, 0.0f);
+  return std::fmin(d * d, 100.0f);
+}
+
+void rt_camera_pan_speed(const rt_camera *cam, float out2[2]) {
+  out2[0] = pan_factor(cam->viewport_width);
+  out2[1] = pan_factor(cam->viewport_height);
+}
+
+void rt_camera_rotate(rt_camera *cam, float delta_x, float delta_y) {
+  float up[3];
+  rt_camera_up(cam, up);
+  const float yaw_sign = up[1] < 0.0f ? 1.0f : -1.0f;
+  const float speed = rt_camera_rotation_speed(cam);
+  cam->yaw += yaw_sign * delta_x * speed;
+  cam->pitch += delta_y * speed;
+}
+
+void rt_camera_projection_matrix(rt_camera *cam, float p[16]) {
+  cam->aspect_ratio = cam->viewport_width / cam->viewport_height;
+  const float fovy = cam->fov * 0.01745329251994329576923690768489f;  // glm::radians
+  const float t = std::tan(fovy / 2.0f);
+  const float n = cam->near_plane, f = cam->far_plane;
+  std::memset(p, 0, 16 * sizeof(float));
+  p[0] = 1.0f / (cam->aspect_ratio * t);
+  p[5] = 1.0f / t;
+  p[10] = (f + n) / (f - n);
+  p[11] = 1.0f;
+  p[14] = -(2.0f * f * n) / (f - n);
+}
+
+void rt_camera_view_matrix(const rt_camera *cam, float view[16]) {
+  const Quat q = orientation_of(*cam);
+  const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+  const float xz = q.x * q.z, xy = q.x * q.y, yz = q.y * q.z;
+  const float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+  float rot[16] = {0};
+  rot[0] = 1.0f - 2.0f * (yy + zz);
+  rot[1] = 2.0f * (xy + wz);
+  rot[2] = 2.0f * (xz - wy);
+  rot[4] = 2.0f * (xy - wz);
+  rot[5] = 1.0f - 2.0f * (xx + zz);
+  rot[6] = 2.0f * (yz + wx);
+  rot[8] = 2.0f * (xz + wy);
+  rot[9] = 2.0f * (yz - wx);
+  rot[10] = 1.0f - 2.0f * (xx + yy);
+  rot[15] = 1.0f;
+  // translate(I, vec3(0)) * rot == rot; the reference inverts that product
+  rt::mat4_inverse(rot, view);
+}
+
+void rt_ubo_set_camera(rt_camera *cam, rt_ubo *ubo) {
+  rt_camera_view_matrix(cam, ubo->view);
+  rt_camera_projection_matrix(cam, ubo->projection);
+  ubo->viewport_size[0] = cam->viewport_width;
+  ubo->viewport_size[1] = cam->viewport_height;
+  ubo->viewport_size[2] = 0.0f;
+  ubo->viewport_size[3] = 0.0f;
+  for (int k = 0; k < 4; ++k) ubo->camera_position[k] = 0.0f;
+}
+
+void rt_default_ubo(rt_camera *cam, rt_ubo *out) {
+  std::memset(out, 0, sizeof *out);
+  rt_camera local;
+  if (!cam) {
+    rt_camera_create(90.0f, 1.0f, 0.01f, 10000.0f, &local);
+    cam = &local;
+  }
+  rt_ubo_set_camera(cam, out);
+  out->render_settings[0] = 50.0f;
+  out->render_settings[1] = 25.0f;
+  const float ground[4] = {0.35f, 0.3f, 0.35f, 1.0f};
+  const float horizon[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+  const float zenith[4] = {0.078f, 0.36f, 0.72f, 1.0f};
+  std::memcpy(out->ground_colour, ground, sizeof ground);
+  std::memcpy(out->sky_colour_horizon, horizon, sizeof horizon);
+  std::memcpy(out->sky_colour_zenith, zenith, sizeof zenith);
+  const float inv_len = 1.0f / std::sqrt(4.0f);  // normalize(vec4(1.0))
+  for (int k = 0; k < 4; ++k) out->sun_position[k] = 1.0f * inv_len;
+  out->sun_focus = 1.0f;
+  out->sun_intensity = 0.0f;
+  out->defocus_strength = 0.0f;
+  out->diverge_strength = 1.0f;
+}
+
+uint32_t rt_default_scene(rt_sphere out3[3]) {
+  std::memset(out3, 0, 3 * sizeof(rt_sphere));
+  auto put = [&](int i, float x, float y, float z, float r, float cr, float cg, float cb,
+                 float smooth, float spec_prob) {
+    rt_sphere &s = out3[i];
+    s.position[0] = x; s.position[1] = y; s.position[2] = z;
+    s.radius = r;
+    s.material.colour[0] = cr; s.material.colour[1] = cg; s.material.colour[2] = cb;
+    s.material.colour[3] = smooth;
+    s.material.specular_colour[0] = s.material.specular_colour[1] = 1.0f;
+    s.material.specular_colour[2] = 1.0f;
+    s.material.specular_colour[3] = spec_prob;
+  };
+  put(0, 0.0f, 0.0f, -5.0f, 1.0f, 0.5f, 0.5f, 0.5f, 1.0f, 0.5f);
+  put(1, 3.0f, 0.0f, -5.0f, 1.0f, 0.8f, 0.2f, 0.2f, 0.5f, 0.0f);
+  put(2, 0.0f, -101.0f, -5.0f, 100.0f, 0.2f, 0.8f, 0.05f, 0.0f, 0.0f);
+  return 3;
+}
+
+int rt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
+                 int flip_y) {
+  if (!path || !rgba8 || !width || !height) {
+    errno = EINVAL;
+    return -1;
+  }
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return -1;
+  std::fprintf(f, "P6\n%u %u\n255\n", width, height);
+  std::vector<uint8_t> row((size_t)width * 3);
+  for (uint32_t y = 0; y < height; ++y) {
+    const uint32_t sy = flip_y ? height - 1 - y : y;
+    const uint8_t *src = rgba8 + (size_t)sy * width * 4;
+    for (uint32_t x = 0; x < width; ++x) {
+      row[3 * (size_t)x + 0] = src[4 * (size_t)x + 0];
+      row[3 * (size_t)x + 1] = src[4 * (size_t)x + 1];
+      row[3 * (size_t)x + 2] = src[4 * (size_t)x + 2];
+    }
+    if (std::fwrite(row.data(), 1, row.size(), f) != row.size()) {
+      std::fclose(f);
+      return -1;
+    }
+  }
+  return std::fclose(f) == 0 ? 0 : -1;
+}
+
+}  // extern "C"

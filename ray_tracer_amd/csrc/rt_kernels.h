@@ -1,0 +1,20 @@
+// Host-callable launchers of the device stages (one .hip file each).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_device_scene.h"
+
+namespace rt {
+
+// rt_megakernel.hip
+hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
+                             const FrameSeq &F, const Outputs &O, hipStream_t stream);
+
+// rt_util.hip
+hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
+                          uint32_t linear_accum, hipStream_t stream);
+hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,
+                             hipStream_t stream);
+
+}  // namespace rt

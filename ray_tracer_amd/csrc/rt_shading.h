@@ -1,0 +1,217 @@
+// The shader's per-pixel program, piece by piece, as device functions shared by the
+// megakernels and the wavefront stages.  Each function cites the lines of
+// assets/shaders/ray_tracing.comp it implements.  The order of RNG draws and of
+// floating-point operations is part of the contract: both kernel organisations call
+// the same functions in the same per-path order and so produce identical bits.
+#pragma once
+
+#include "rt_device_math.h"
+#include "rt_device_scene.h"
+
+namespace rt {
+
+// ---- camera ---------------------------------------------------------------------
+// column-major mat4 * vec4, one x,y,z,w fma chain per output row
+__device__ __forceinline__ float mat_row(const float *m, int r, float x, float y, float z, float w) {
+  float acc = m[0 + r] * x;
+  acc = __builtin_fmaf(m[4 + r], y, acc);
+  acc = __builtin_fmaf(m[8 + r], z, acc);
+  acc = __builtin_fmaf(m[12 + r], w, acc);
+  return acc;
+}
+
+// screenToWorldDirection (ray_tracing.comp:224-237).  Depends only on the pixel,
+// so it is evaluated once per pixel instead of once per sample.
+__device__ __forceinline__ f3 pixel_direction(const Params &P, uint32_t px, uint32_t py) {
+  float cx = ieee_div(2.0f * (float)px, P.viewport_w) - 1.0f;
+  float cy = ieee_div(2.0f * (float)py, P.viewport_h) - 1.0f;
+  float ex = mat_row(P.inv_proj, 0, cx, cy, -1.0f, 1.0f);
+  float ey = mat_row(P.inv_proj, 1, cx, cy, -1.0f, 1.0f);
+  f3 w = mk3(mat_row(P.inv_view, 0, ex, ey, -1.0f, 0.0f), mat_row(P.inv_view, 1, ex, ey, -1.0f, 0.0f),
+             mat_row(P.inv_view, 2, ex, ey, -1.0f, 0.0f));
+  return ieee_normalize(w);
+}
+
+// rngState seed (ray_tracing.comp:80-82): x*W + y, plus int(frame)*719393
+__device__ __forceinline__ uint32_t pixel_seed(const Params &P, uint32_t px, uint32_t py,
+                                               uint32_t frame) {
+  return px * P.width + py + frame * 719393u;
+}
+
+// Primary ray of one sample (ray_tracing.comp:86-93): four RNG draws, defocus first.
+template <bool STRICT>
+__device__ __forceinline__ void sample_ray(const Params &P, f3 base_dir, uint32_t &rng, f3 &o,
+                                           f3 &d) {
+  using M = Math<STRICT>;
+  float c, s;
+  // randomPointInCircle (ray_tracing.comp:134-138): angle draw, then radius draw
+  float u_angle = pcg_float(rng);
+  float u_rad = pcg_float(rng);
+  if (STRICT || P.defocus != 0.0f) {
+    M::circle(u_angle, c, s);
+    float r = M::sqrt(u_rad);
+    float jx = M::jitter(c * r, P.defocus, P.fwidth, P.defocus_over_w);
+    float jy = M::jitter(s * r, P.defocus, P.fwidth, P.defocus_over_w);
+    o = mk3(P.cam_x + M::div(jx, P.fwidth), P.cam_y + M::div(jy, P.fheight), P.cam_z + 0.0f);
+  } else {
+    o = mk3(P.cam_x + 0.0f, P.cam_y + 0.0f, P.cam_z + 0.0f);
+  }
+  u_angle = pcg_float(rng);
+  u_rad = pcg_float(rng);
+  M::circle(u_angle, c, s);
+  float r = M::sqrt(u_rad);
+  d = mk3(base_dir.x + M::jitter(c * r, P.diverge, P.fwidth, P.diverge_over_w),
+          base_dir.y + M::jitter(s * r, P.diverge, P.fwidth, P.diverge_over_w), base_dir.z + 0.0f);
+}
+
+// ---- closest hit, brute force (ray_tracing.comp:145-190) ---------------------------
+//
+// The shader's quadratic uses b = 2*dot(oc,d), disc = b*b - 4ac, dst = (-b - sqrt(disc))/(2a).
+// With bh = dot(oc,d): disc = 4*(bh*bh - a*c) and dst = (-bh - sqrt(bh*bh - a*c))/a, and
+// because scaling by 2 and 4 is exact in binary floating point (no overflow or
+// underflow in play) every rounded intermediate is the exact half/quarter of the
+// shader's, and dst is the same float.  a = dot(d,d) is per ray.
+//
+// Rejections taken before the expensive IEEE sqrt and divide, none of which changes
+// a result:
+//   bh > 0           -> -bh - sqrt(..) < 0, so dst < 0: the shader rejects it too
+//   n >= best_n      -> n/a >= best_n/a after rounding (a > 0, rounding is monotonic),
+//                       so "dst < closest.dst" is false
+// A numerator in (-1e-30, 0) is let through to the exact test because its quotient
+// may round to -0, which the shader's "dst >= 0" accepts.
+struct Hit {
+  float dst;
+  int idx;  // -1: miss
+};
+
+__device__ __forceinline__ void sphere_candidate(float4 g, int i, f3 o, f3 d, float a, float &best_n,
+                                                 Hit &best) {
+  f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  float bh = dot(oc, d);
+  float c = dot(oc, oc) - g.w;
+  float disc = __builtin_fmaf(bh, bh, -(a * c));
+  if (disc >= 0.0f && bh <= 0.0f) {
+    float n = -bh - ieee_sqrt(disc);
+    if (n < best_n && n > -1e-30f) {
+      float q = ieee_div(n, a);
+      if (q >= 0.0f && q < best.dst) {
+        best.dst = q;
+        best.idx = i;
+        best_n = n;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d) {
+  Hit best;
+  best.dst = 3.402823466e+38f;
+  best.idx = -1;
+  float best_n = __builtin_inff();
+  float a = dot(d, d);
+  const uint32_t n = S.n_spheres;
+  for (uint32_t i = 0; i < n; ++i) sphere_candidate(S.geom[i], (int)i, o, d, a, best_n, best);
+  return best;
+}
+
+// ---- environment (ray_tracing.comp:239-250) ----------------------------------------
+__device__ __forceinline__ float clamp01(float t) { return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t); }
+__device__ __forceinline__ float smoothstep_div(float e0, float e1, float x) {
+  float t = clamp01(ieee_div(x - e0, e1 - e0));
+  return (t * t) * (3.0f - 2.0f * t);
+}
+
+template <bool STRICT>
+__device__ __forceinline__ f3 environment(const Params &P, f3 d) {
+  using M = Math<STRICT>;
+  float sky_t = M::pow(smoothstep_div(0.0f, 0.4f, d.y), 0.35f);
+  float g2s = smoothstep_div(-0.01f, 0.0f, d.y);
+  f3 sky = mix3(mk3(P.horizon[0], P.horizon[1], P.horizon[2]),
+                mk3(P.zenith[0], P.zenith[1], P.zenith[2]), sky_t);
+  float sd = dot(d, mk3(P.sun[0], P.sun[1], P.sun[2]));
+  float sun = M::pow(sd > 0.0f ? sd : 0.0f, P.sun_focus) * P.sun_intensity;
+  f3 comp = mix3(mk3(P.ground[0], P.ground[1], P.ground[2]), sky, g2s);
+  float s = sun * (g2s >= 1.0f ? 1.0f : 0.0f);
+  return mk3(comp.x + s, comp.y + s, comp.z + s);
+}
+
+// ---- scatter (ray_tracing.comp:199-213) ---------------------------------------------
+// randomValueNormalDistribution (ray_tracing.comp:121-125): theta draw before rho draw
+template <bool STRICT>
+__device__ __forceinline__ float normal_draw(uint32_t &rng) {
+  using M = Math<STRICT>;
+  float u1 = pcg_float(rng);
+  float u2 = pcg_float(rng);
+  return M::sqrt(M::neg2log(u2)) * M::box_cos(u1);
+}
+
+// On a hit: new origin and direction, emitted light added, throughput updated.
+// centre is the hit sphere's centre, m its three material vectors.
+template <bool STRICT>
+__device__ __forceinline__ void scatter(f3 centre, float4 m_colour, float4 m_emission,
+                                        float4 m_specular, float dst, uint32_t &rng, f3 &o, f3 &d,
+                                        f3 &light, f3 &colour) {
+  using M = Math<STRICT>;
+  f3 p = fma3(d, dst, o);                    // hitPoint = origin + dir*dst (:164)
+  f3 n = ieee_normalize(p - centre);         // (:165)
+  o = p;                                     // (:201)
+  float x = normal_draw<STRICT>(rng);        // randomDirection (:127-132)
+  float y = normal_draw<STRICT>(rng);
+  float z = normal_draw<STRICT>(rng);
+  f3 rd = M::normalize(mk3(x, y, z));
+  f3 diffuse = M::normalize(n + rd);         // (:202)
+  float dn2 = 2.0f * dot(n, d);              // reflect(I, N) = I - 2 dot(N, I) N (:203)
+  f3 spec = mk3(__builtin_fmaf(-dn2, n.x, d.x), __builtin_fmaf(-dn2, n.y, d.y),
+                __builtin_fmaf(-dn2, n.z, d.z));
+  float is_spec = (m_specular.w >= pcg_float(rng)) ? 1.0f : 0.0f;  // (:204-205)
+  d = mix3(diffuse, spec, m_colour.w * is_spec);                   // (:206-207)
+  f3 emitted = mk3(m_emission.x * m_emission.w, m_emission.y * m_emission.w,
+                   m_emission.z * m_emission.w);                  // (:209-210)
+  light = fma3v(emitted, colour, light);                           // (:211)
+  colour = colour * mix3(mk3(m_colour.x, m_colour.y, m_colour.z),
+                         mk3(m_specular.x, m_specular.y, m_specular.z), is_spec);  // (:212-213)
+}
+
+// ---- per-frame pixel epilogue (ray_tracing.comp:98-109) ------------------------------
+__device__ __forceinline__ uint32_t unorm8(float v) {
+  if (!(v > 0.0f)) return 0u;  // NaN and negatives store 0
+  if (v > 1.0f) v = 1.0f;
+  return (uint32_t)__builtin_rintf(v * 255.0f);
+}
+
+// mean over samples, gamma, float accumulation, and the shader's progressive blend
+// carried in registers: img holds the 8-bit texel as the shader would load it.
+__device__ __forceinline__ void frame_epilogue(const Params &P, f3 total, float frame_f,
+                                               uint32_t linear_accum, float4 &acc, uchar4 &img) {
+  f3 mean = mk3(ieee_div(total.x, P.spp_f), ieee_div(total.y, P.spp_f), ieee_div(total.z, P.spp_f));
+  f3 g = mk3(ieee_sqrt(mean.x), ieee_sqrt(mean.y), ieee_sqrt(mean.z));
+  f3 c = linear_accum ? mean : g;
+  acc.x += c.x;
+  acc.y += c.y;
+  acc.z += c.z;
+  acc.w += 1.0f;
+  float w = ieee_div(1.0f, frame_f + 1.0f);
+  float omw = 1.0f - w;
+  img.x = (unsigned char)unorm8(__builtin_fmaf(g.x, w, ieee_div((float)img.x, 255.0f) * omw));
+  img.y = (unsigned char)unorm8(__builtin_fmaf(g.y, w, ieee_div((float)img.y, 255.0f) * omw));
+  img.z = (unsigned char)unorm8(__builtin_fmaf(g.z, w, ieee_div((float)img.z, 255.0f) * omw));
+  img.w = (unsigned char)unorm8(__builtin_fmaf(1.0f, w, 1.0f * omw));
+}
+
+// 16x16 pixel tiles per 256-thread block; each wave64 owns an 8x8 sub-tile so the
+// lanes of a wave see neighbouring pixels (similar path lengths, shared cache lines).
+__device__ __forceinline__ void pixel_of_thread(uint32_t &px, uint32_t &py) {
+  uint32_t t = threadIdx.x;
+  uint32_t wave = t >> 6, lane = t & 63u;
+  px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+  py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+
+// wave-level sum of a 32-bit count, result valid in every lane
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace rt

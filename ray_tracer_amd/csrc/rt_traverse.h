@@ -1,0 +1,97 @@
+// Closest-hit search through the linear BVH.
+//
+// The result must be the one the shader's brute-force loop (ray_tracing.comp:172-190)
+// gives: the smallest dst, and among equal dst the LOWEST sphere index (its strict
+// "<" keeps the first one found in index order).  Traversal order is arbitrary, so
+// ties are resolved explicitly on the original index.
+//
+// Each lane keeps its traversal stack in LDS, entry-major ([entry][thread]): lane l
+// always touches bank l mod 32 whatever its depth, and lanes l / l+32 belong to
+// different LDS lane groups, so pushes and pops never conflict.
+#pragma once
+
+#include "rt_shading.h"
+
+namespace rt {
+
+constexpr int kBvhStack = 32;   // entries per lane; the host checks the tree depth
+constexpr int kBlockThreads = 256;
+
+__device__ __forceinline__ void sphere_candidate_tie(float4 g, int idx, f3 o, f3 d, float a,
+                                                     float &best_n, Hit &best) {
+  f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  float bh = dot(oc, d);
+  float c = dot(oc, oc) - g.w;
+  float disc = __builtin_fmaf(bh, bh, -(a * c));
+  if (disc >= 0.0f && bh <= 0.0f) {
+    float n = -bh - ieee_sqrt(disc);
+    if (n <= best_n && n > -1e-30f) {
+      float q = ieee_div(n, a);
+      if (q >= 0.0f && (q < best.dst || (q == best.dst && idx < best.idx))) {
+        best.dst = q;
+        best.idx = idx;
+        best_n = n;
+      }
+    }
+  }
+}
+
+// entry distance of the ray into a box, +inf when it misses or the box is beyond limit
+__device__ __forceinline__ float slab_entry(const float lo[3], const float hi[3], f3 o, f3 inv_d,
+                                            float limit) {
+  float x0 = (lo[0] - o.x) * inv_d.x, x1 = (hi[0] - o.x) * inv_d.x;
+  float y0 = (lo[1] - o.y) * inv_d.y, y1 = (hi[1] - o.y) * inv_d.y;
+  float z0 = (lo[2] - o.z) * inv_d.z, z1 = (hi[2] - o.z) * inv_d.z;
+  float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+  float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), limit));
+  return tn <= tf ? tn : __builtin_inff();
+}
+
+__device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d) {
+  __shared__ int stack[kBvhStack][kBlockThreads];
+  const int tid = threadIdx.x;
+  Hit best;
+  best.dst = 3.402823466e+38f;
+  best.idx = 0x7fffffff;
+  float best_n = __builtin_inff();
+  const float a = dot(d, d);
+  const f3 inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
+                       __builtin_amdgcn_rcpf(d.z));
+  if (S.n_spheres == 1u) {
+    sphere_candidate_tie(S.sorted_geom[0], (int)S.sorted_prim[0], o, d, a, best_n, best);
+  } else {
+    int sp = 0;
+    int node = 0;
+    while (true) {
+      const BvhNode nd = S.nodes[node];
+      // the distance limit carries slack: box arithmetic rounds, the sphere test decides
+      const float limit = __builtin_fmaf(best.dst, 1.0e-4f, best.dst);
+      float t0 = slab_entry(nd.lo0, nd.hi0, o, inv_d, limit);
+      float t1 = slab_entry(nd.lo1, nd.hi1, o, inv_d, limit);
+      int c0 = nd.child0, c1 = nd.child1;
+      if (t0 < __builtin_inff() && c0 < 0) {
+        sphere_candidate_tie(S.sorted_geom[~c0], (int)S.sorted_prim[~c0], o, d, a, best_n, best);
+        t0 = __builtin_inff();
+      }
+      if (t1 < __builtin_inff() && c1 < 0) {
+        sphere_candidate_tie(S.sorted_geom[~c1], (int)S.sorted_prim[~c1], o, d, a, best_n, best);
+        t1 = __builtin_inff();
+      }
+      const bool go0 = t0 < __builtin_inff(), go1 = t1 < __builtin_inff();
+      if (go0 && go1) {
+        const bool first0 = t0 <= t1;
+        stack[sp++][tid] = first0 ? c1 : c0;
+        node = first0 ? c0 : c1;
+      } else if (go0 || go1) {
+        node = go0 ? c0 : c1;
+      } else {
+        if (sp == 0) break;
+        node = stack[--sp][tid];
+      }
+    }
+  }
+  if (best.idx == 0x7fffffff) best.idx = -1;
+  return best;
+}
+
+}  // namespace rt

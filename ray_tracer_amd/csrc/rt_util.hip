@@ -1,0 +1,72 @@
+// Small device passes: accumulation image -> 8-bit image, and the math test hook.
+#include "rt_kernels.h"
+#include "rt_shading.h"
+
+namespace rt {
+
+// mean over frames, gamma if the sums are linear, then the rgba8 store conversion
+__global__ __launch_bounds__(256) void k_resolve(const float4 *__restrict__ accum,
+                                                 uchar4 *__restrict__ rgba8, uint32_t n,
+                                                 uint32_t linear_accum) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 a = accum[i];
+    float r = ieee_div(a.x, a.w), g = ieee_div(a.y, a.w), b = ieee_div(a.z, a.w);
+    if (linear_accum) {
+      r = ieee_sqrt(r);
+      g = ieee_sqrt(g);
+      b = ieee_sqrt(b);
+    }
+    rgba8[i] = make_uchar4((unsigned char)unorm8(r), (unsigned char)unorm8(g),
+                           (unsigned char)unorm8(b), 255);
+  }
+}
+
+hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
+                          uint32_t linear_accum, hipStream_t stream) {
+  uint32_t blocks = (n_pixels + 255u) / 256u;
+  if (blocks > 2048u) blocks = 2048u;
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, stream, accum, rgba8, n_pixels,
+                     linear_accum);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_debug_eval(int op, const float *__restrict__ a,
+                                                    const float *__restrict__ b,
+                                                    float *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float x = a[i], y = b ? b[i] : 0.0f, r;
+    switch (op) {
+      case 0: r = ieee_sqrt(x); break;
+      case 1: r = ieee_div(x, y); break;
+      case 2: r = pm::sin(x); break;
+      case 3: r = pm::cos(x); break;
+      case 4: r = pm::log(x); break;
+      case 5: r = pm::log2(x); break;
+      case 6: r = pm::exp2(x); break;
+      case 7: r = pm::pow(x, y); break;
+      case 8: r = __builtin_amdgcn_sinf(x * 0.15915494309189535f); break;
+      case 9: r = __builtin_amdgcn_cosf(x * 0.15915494309189535f); break;
+      case 10: r = 0.693147181f * __builtin_amdgcn_logf(x); break;
+      case 11: r = __builtin_amdgcn_logf(x); break;
+      case 12: r = __builtin_amdgcn_exp2f(x); break;
+      case 13: r = Math<false>::pow(x, y); break;
+      case 14: r = __builtin_amdgcn_sqrtf(x); break;
+      case 15: r = __builtin_amdgcn_rsqf(x); break;
+      default: r = 0.0f; break;
+    }
+    out[i] = r;
+  }
+}
+
+hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,
+                             hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_debug_eval, dim3((unsigned)blocks), dim3(256), 0, stream, op, a, b, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace rt

@@ -1,0 +1,138 @@
+"""ctypes binding of the CPU oracle (oracle/librt_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "librt_oracle.so")
+L = C.CDLL(SO)
+
+MATH_PORTABLE, MATH_LIBM = 0, 1
+ACCUM_GAMMA, ACCUM_LINEAR = 0, 1
+
+L.rto_next_random.restype = C.c_uint32
+L.rto_random_value.restype = C.c_float
+for _n in ("sin", "cos", "log", "log2", "exp2"):
+    f = getattr(L, "rto_pm_" + _n)
+    f.restype = C.c_float
+    f.argtypes = [C.c_float]
+L.rto_pm_pow.restype = C.c_float
+L.rto_pm_pow.argtypes = [C.c_float, C.c_float]
+L.rto_unorm8.restype = C.c_uint8
+L.rto_unorm8.argtypes = [C.c_float]
+L.rto_default_spheres.restype = C.c_uint32
+L.rto_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                         C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                         C.c_void_p, C.c_void_p, C.c_int]
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "fov", "near_", "far_", "pitch", "yaw", "aspect_ratio", "distance", "viewport_width",
+        "viewport_height")]
+
+
+def camera_create(fov, aspect, near, far):
+    cam = Camera()
+    L.rto_camera_create(C.c_float(fov), C.c_float(aspect), C.c_float(near), C.c_float(far),
+                        C.byref(cam))
+    return cam
+
+
+def _vec(fn, cam, n):
+    out = (C.c_float * n)()
+    fn(C.byref(cam), out)
+    return np.array(out, dtype=np.float32)
+
+
+def camera_view(cam):
+    return _vec(L.rto_camera_view, cam, 16)
+
+
+def camera_projection(cam):
+    return _vec(L.rto_camera_projection, cam, 16)
+
+
+def camera_up(cam):
+    return _vec(L.rto_camera_up, cam, 3)
+
+
+def camera_rotate(cam, dx, dy):
+    L.rto_camera_rotate(C.byref(cam), C.c_float(dx), C.c_float(dy))
+
+
+def mat4_inverse(m):
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    out = np.empty(16, dtype=np.float32)
+    L.rto_mat4_inverse(m.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def default_ubo(cam=None):
+    ubo = np.zeros(68, dtype=np.float32)
+    L.rto_default_ubo(C.byref(cam) if cam is not None else None, ubo.ctypes.data_as(C.c_void_p))
+    return ubo
+
+
+def default_spheres():
+    s = np.zeros((3, 16), dtype=np.float32)
+    assert L.rto_default_spheres(s.ctypes.data_as(C.c_void_p)) == 3
+    return s
+
+
+def pcg_stream(seed, n):
+    """[(state_after, raw_u32, float_value)] for n successive draws."""
+    s = C.c_uint32(seed)
+    out = []
+    for _ in range(n):
+        before = C.c_uint32(s.value)
+        raw = L.rto_next_random(C.byref(s))
+        val = L.rto_random_value(C.byref(before))
+        out.append((s.value, raw, np.float32(val)))
+    return out
+
+
+def pm(name, x, y=None):
+    """Elementwise portable-math kernel over numpy arrays (slow Python loop: small inputs)."""
+    x = np.asarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    f = getattr(L, "rto_pm_" + name)
+    flat_x, flat_o = x.ravel(), out.ravel()
+    if y is None:
+        for i in range(flat_x.size):
+            flat_o[i] = f(float(flat_x[i]))
+    else:
+        flat_y = np.asarray(y, dtype=np.float32).ravel()
+        for i in range(flat_x.size):
+            flat_o[i] = f(float(flat_x[i]), float(flat_y[i]))
+    return out
+
+
+def render(ubo, spheres, width, height, first_frame=0, n_frames=1, stride=1,
+           math_mode=MATH_PORTABLE, accum_mode=ACCUM_GAMMA, threads=8, accum=None, rgba8=None):
+    """Returns dict(accum, rgba8, ids, rays).  accum/rgba8 may be passed in to continue."""
+    ubo = np.ascontiguousarray(ubo, dtype=np.float32)
+    spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 16)
+    if accum is None:
+        accum = np.zeros((height, width, 4), dtype=np.float32)
+    if rgba8 is None:
+        rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
+    ids = np.full((height, width), -1, dtype=np.int32)
+    rays = C.c_uint64(0)
+    rc = L.rto_render(ubo.ctypes.data_as(C.c_void_p), spheres.ctypes.data_as(C.c_void_p),
+                      spheres.shape[0], width, height, first_frame, n_frames, stride, math_mode,
+                      accum_mode, accum.ctypes.data_as(C.c_void_p),
+                      rgba8.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                      C.byref(rays), threads)
+    assert rc == 0
+    return dict(accum=accum, rgba8=rgba8, ids=ids, rays=int(rays.value))
+
+
+def resolve_rgba8(accum, accum_mode=ACCUM_GAMMA):
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    h, w = accum.shape[:2]
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    L.rto_resolve_rgba8(accum.ctypes.data_as(C.c_void_p), h * w, accum_mode,
+                        out.ctypes.data_as(C.c_void_p))
+    return out
