@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (every path segment) of the path-tracing hot path.
+
+Workload (BASELINE.json configs[1]): the reference's default 3-sphere scene at
+1920x1080, 64 samples per pixel per frame, at most 25 bounces, camera viewport set to
+the image size.  One step = one frame batch of the hot path per GPU: zero the float
+accumulation image, render one 64-spp frame into it, (N > 1: sum the N accumulation
+images onto rank 0 with one RCCL reduce over xGMI,) resolve to the 8-bit image.  With
+N GPUs rank r renders frame index step*N + r -- the sample-wise split whose frames
+carry the shader's own per-frame RNG streams -- so per-GPU work is fixed (weak
+scaling) and every step yields an N*64-spp image on rank 0.
+
+Prints ONE JSON line on rank 0.  Launch for N > 1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# peaks from the MI355X micro-architecture guide
+PEAK_FP32_VALU_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 64, 25
+
+
+def algorithmic_flops(rays: float, samples: float, n_spheres: int) -> float:
+    """FP32 flops the shader's arithmetic needs for this many path segments, counted from
+    ray_tracing.comp with a = dot(d,d) hoisted and an FMA as 2 flops:
+      per segment        5 + 20 * n_spheres      (ray_tracing.comp:152-156)
+      per hit bounce     23 + 100                (hit point, normal: :159-165; scatter: :199-213)
+      per escaping path  40                      (getEnvironmentLight, :239-250)
+      per sample         30                      (primary ray, :86-93,224-237)
+    hits = rays - samples (every path ends in exactly one miss; paths cut by the bounce
+    limit are ~1e-4 of the total and are counted as misses)."""
+    hits = max(rays - samples, 0.0)
+    return rays * (5 + 20 * n_spheres) + hits * 123.0 + samples * 70.0
+
+
+def cpu_baseline(ubo, spheres, threads: int):
+    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload:
+    same scene, resolution and bounce limit, 4 spp instead of 64."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as oracle
+    ubo = ubo.copy()
+    spp = 4
+    ubo[40] = float(spp)
+    t0 = time.perf_counter()
+    res = oracle.render(ubo, spheres, WIDTH, HEIGHT, 0, 1, 1, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": res["rays"] / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"same scene {WIDTH}x{HEIGHT}, {spp} spp (of {SPP}), maxBounce {BOUNCES}, "
+                  f"frame 0: {res['rays']} rays in {dt:.2f} s",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["megakernel", "wavefront", "nested"], default="megakernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ray_tracer_amd as rt
+    from ray_tracer_amd.distributed import frame_partition, reduce_accumulation
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    mode = {"megakernel": rt.MODE_MEGAKERNEL, "wavefront": rt.MODE_WAVEFRONT,
+            "nested": rt.MODE_MEGAKERNEL_NESTED}[args.mode]
+    ubo = rt.make_ubo(WIDTH, HEIGHT, SPP, BOUNCES)
+    spheres = rt.default_scene()
+    n_spheres = spheres.shape[0]
+
+    # the accumulation image lives in a torch tensor so RCCL can reduce it in place
+    accum = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    r = rt.Renderer(WIDTH, HEIGHT, mode=mode, flags=0, device=local_rank,
+                    stream=stream.cuda_stream, accum_buffer=accum.data_ptr())
+    r.set_params(ubo)
+    r.set_spheres(spheres)
+
+    def step(i: int) -> None:
+        accum.zero_()
+        first, count, stride = frame_partition(i * world, world, rank, world)
+        r.render(first, count, stride)
+        reduce_accumulation(accum, dst=0)
+        if rank == 0:
+            r.resolve()
+
+    def fence() -> None:
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    st0 = r.stats()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st1 = r.stats()
+
+    rays = float(st1.rays - st0.rays)
+    kernel_ms = float(st1.total_render_ms - st0.total_render_ms)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        t = torch.tensor([rays], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_rays = float(t.item())
+    else:
+        total_rays = rays
+
+    if rank == 0:
+        samples = float(WIDTH * HEIGHT * SPP * args.steps)  # per GPU
+        launch_ms = kernel_ms / max(args.steps, 1)          # rank 0's render launches, HIP events
+        flops = algorithmic_flops(rays, samples, n_spheres) / max(args.steps, 1)
+        achieved = flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec (all bounces)",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"reference default scene (3 spheres, main.cpp:517-538), {WIDTH}x{HEIGHT}, "
+                            f"{SPP} spp/frame, maxBounce {BOUNCES}, 1 frame per GPU per step "
+                            "(BASELINE.json configs[1])",
+                "mode": args.mode,
+                "math": "fast (hardware transcendentals; geometry IEEE)",
+                "parallelism": f"frame-split x{world}" + (" + RCCL reduce" if world > 1 else ""),
+                "ms_per_frame_1080p_64spp": launch_ms,
+                "rays_per_frame": rays / max(args.steps, 1),
+            },
+            "roofline": {
+                "bound": "valu",
+                "kernel": {"megakernel": "k_mega_regen<fast,brute>", "nested": "k_mega_nested<fast,brute>",
+                           "wavefront": "wavefront stages"}[args.mode],
+                "achieved": achieved,
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "traffic": None,
+                "launch_ms": launch_ms,
+                "algorithmic_flops_per_launch": flops,
+                "note": "branchy FP32 vector work, no dense contraction: priced against the FP32 "
+                        "vector peak (= the f32 MFMA peak); HBM traffic is ~50 B/pixel/frame",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(ubo, spheres, threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,8 +73,11 @@ struct rt_ctx {
   int32_t *d_ids = nullptr;
   unsigned long long *d_rays = nullptr;
 
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  bool timing_pending = false;
+  // HIP event pairs around each rt_render; resolved lazily so rendering never waits
+  struct EventPair {
+    hipEvent_t begin = nullptr, end = nullptr;
+  };
+  std::vector<EventPair> ev_free, ev_pending;
   uint64_t frames = 0;
   float last_ms = 0.f, total_ms = 0.f;
   uint32_t last_launches = 0;
@@ -82,15 +85,36 @@ struct rt_ctx {
 
 namespace {
 
-int collect_timing(rt_ctx *c) {
-  if (c->timing_pending) {
+constexpr size_t kMaxPendingEvents = 512;
+
+// folds finished event pairs into the statistics; keep_newest pairs may stay pending
+int collect_timing(rt_ctx *c, size_t keep_newest) {
+  while (c->ev_pending.size() > keep_newest) {
+    rt_ctx::EventPair p = c->ev_pending.front();
     float ms = 0.f;
-    RT_HIP(hipEventSynchronize(c->ev_end));
-    RT_HIP(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+    RT_HIP(hipEventSynchronize(p.end));
+    RT_HIP(hipEventElapsedTime(&ms, p.begin, p.end));
     c->last_ms = ms;
     c->total_ms += ms;
-    c->timing_pending = false;
+    c->ev_pending.erase(c->ev_pending.begin());
+    c->ev_free.push_back(p);
   }
+  return RT_OK;
+}
+
+int acquire_events(rt_ctx *c, rt_ctx::EventPair *out) {
+  if (c->ev_free.empty()) {
+    if (c->ev_pending.size() >= kMaxPendingEvents) {
+      if (collect_timing(c, kMaxPendingEvents / 2) != RT_OK) return RT_ERR_DEVICE;
+    } else {
+      rt_ctx::EventPair p;
+      RT_HIP(hipEventCreate(&p.begin));
+      RT_HIP(hipEventCreate(&p.end));
+      c->ev_free.push_back(p);
+    }
+  }
+  *out = c->ev_free.back();
+  c->ev_free.pop_back();
   return RT_OK;
 }
 
@@ -159,8 +183,6 @@ int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
   if ((e = hipMalloc(&c->d_ids, c->n_pixels * sizeof(int32_t))) != hipSuccess)
     return bail(e, "hipMalloc(ids)");
   if ((e = hipMalloc(&c->d_rays, 256)) != hipSuccess) return bail(e, "hipMalloc(rays)");
-  if ((e = hipEventCreate(&c->ev_begin)) != hipSuccess) return bail(e, "hipEventCreate");
-  if ((e = hipEventCreate(&c->ev_end)) != hipSuccess) return bail(e, "hipEventCreate");
   int rc = rt_clear(c);
   if (rc != RT_OK) {
     rt_destroy(c);
@@ -182,8 +204,11 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_material) hipFree(c->d_material);
   c->bvh.release();
   c->wf.release();
-  if (c->ev_begin) hipEventDestroy(c->ev_begin);
-  if (c->ev_end) hipEventDestroy(c->ev_end);
+  for (auto &p : c->ev_pending) c->ev_free.push_back(p);
+  for (auto &p : c->ev_free) {
+    hipEventDestroy(p.begin);
+    hipEventDestroy(p.end);
+  }
   delete c;
   return RT_OK;
 }
@@ -198,7 +223,8 @@ int rt_clear(rt_ctx *c) {
   c->frames = 0;
   c->last_ms = c->total_ms = 0.f;
   c->last_launches = 0;
-  c->timing_pending = false;
+  for (auto &p : c->ev_pending) c->ev_free.push_back(p);
+  c->ev_pending.clear();
   return RT_OK;
 }
 
@@ -291,7 +317,8 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
   if (n_frames == 0) return RT_OK;
   if (frame_stride == 0) return fail(RT_ERR_INVALID, "rt_render: frame_stride must be >= 1");
   RT_HIP(hipSetDevice(c->device));
-  if (collect_timing(c) != RT_OK) return RT_ERR_DEVICE;
+  rt_ctx::EventPair ev;
+  if (acquire_events(c, &ev) != RT_OK) return RT_ERR_DEVICE;
 
   rt::FrameSeq F{first_frame, n_frames, frame_stride};
   rt::Outputs O{};
@@ -304,19 +331,26 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
   const bool strict = (c->flags & RT_FLAG_STRICT_MATH) != 0;
   const bool degenerate = c->P.n_spp < 1 || c->P.n_bounce < 1;
 
-  RT_HIP(hipEventRecord(c->ev_begin, c->stream));
+  hipError_t he = hipEventRecord(ev.begin, c->stream);
   uint32_t launches = 0;
-  if (c->mode == RT_MODE_WAVEFRONT && !degenerate) {
-    std::string err;
-    int rc = c->wf.render(strict, c->use_bvh, c->P, S, F, O, c->stream, &launches, &err);
-    if (rc != RT_OK) return fail(rc, "rt_render: wavefront: %s", err.c_str());
-  } else {
-    const bool nested = degenerate || c->mode == RT_MODE_MEGAKERNEL_NESTED;
-    RT_HIP(rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream));
-    launches = 1;
+  int rc = RT_OK;
+  std::string err;
+  if (he == hipSuccess) {
+    if (c->mode == RT_MODE_WAVEFRONT && !degenerate) {
+      rc = c->wf.render(strict, c->use_bvh, c->P, S, F, O, c->stream, &launches, &err);
+    } else {
+      const bool nested = degenerate || c->mode == RT_MODE_MEGAKERNEL_NESTED;
+      he = rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream);
+      launches = 1;
+    }
   }
-  RT_HIP(hipEventRecord(c->ev_end, c->stream));
-  c->timing_pending = true;
+  if (he == hipSuccess && rc == RT_OK) he = hipEventRecord(ev.end, c->stream);
+  if (he != hipSuccess || rc != RT_OK) {
+    c->ev_free.push_back(ev);
+    if (rc != RT_OK) return fail(rc, "rt_render: wavefront: %s", err.c_str());
+    return fail(RT_ERR_DEVICE, "rt_render: %s", hipGetErrorString(he));
+  }
+  c->ev_pending.push_back(ev);
   c->frames += n_frames;
   c->last_launches = launches;
   return RT_OK;
@@ -370,7 +404,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
   if (!c || !out) return fail(RT_ERR_INVALID, "rt_get_stats: null argument");
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
-  if (collect_timing(c) != RT_OK) return RT_ERR_DEVICE;
+  if (collect_timing(c, 0) != RT_OK) return RT_ERR_DEVICE;
   unsigned long long rays = 0;
   RT_HIP(hipMemcpy(&rays, c->d_rays, sizeof rays, hipMemcpyDeviceToHost));
   std::memset(out, 0, sizeof *out);

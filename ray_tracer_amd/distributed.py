@@ -1,0 +1,37 @@
+"""Multi-GPU sharding of one image: progressive frames are split across ranks and the
+float accumulation images are summed with one reduce.
+
+The shader seeds every pixel with ``pixelIndex + frame * 719393`` (ray_tracing.comp:80-82)
+and averages frames with equal weight (:106-107), so frames are independent sample
+batches: rank r of W renders frames r, r+W, r+2W, ... into a private accumulation image
+and one sum over ranks gives the same image one device would accumulate (up to the
+order of float additions).  Splitting inside a frame's sample loop would not reproduce
+the RNG streams, because a pixel's state advances sequentially through its samples.
+
+One process per GPU; the reduce is ``torch.distributed.reduce`` (RCCL over xGMI with the
+``nccl`` backend, gloo on CPU in the tests).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def frame_partition(first_frame: int, n_frames: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(first, count, stride) of the frames rank ``rank`` renders out of
+    first_frame .. first_frame + n_frames - 1.  Ranks past the frame count get count 0."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"rank {rank} of world {world}")
+    if n_frames < 0:
+        raise ValueError("n_frames must be >= 0")
+    count = (n_frames - rank + world - 1) // world if n_frames > rank else 0
+    return first_frame + rank, count, world
+
+
+def reduce_accumulation(accum, dst: int = 0):
+    """Sum the accumulation images (any float tensor of identical shape on every rank)
+    onto rank ``dst``.  Returns the tensor; its contents are the sum only on ``dst``."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+    return accum

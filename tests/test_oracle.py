@@ -1,0 +1,203 @@
+"""The CPU oracle against closed-form known answers and the committed golden fixtures.
+
+The reference has no tests or golden vectors for this path, so the anchors are values
+that follow directly from the shader text (ray_tracing.comp) and host code (main.cpp,
+camera.cpp): PCG integer streams, the exact float constants, the primary-hit census of
+the reference's own 800x608 window, centre-pixel distance, default matrices.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def py_pcg(state):
+    """ray_tracing.comp:112-117 on Python integers (independent of the C code)."""
+    state = (state * 747796405 + 2891336453) & 0xFFFFFFFF
+    r = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return state, ((r >> 22) ^ r) & 0xFFFFFFFF
+
+
+def test_pcg_known_answers(oracle):
+    # first draws for four seeds, derived by hand-evaluating the shader's integer formula
+    kat = {
+        0: [(2891336453, 129708002, 0.0301999971), (1192405134, 582399676, 0.135600492),
+            (568162667, 1006035121, 0.234235808), (878960812, 1462727737, 0.340567827)],
+        1: [(3639132858, 2831084092, 0.659163117), (1098935943, 645514520, 0.150295556),
+            (3968020856, 2544563910, 0.592452466), (3079081181, 710022002, 0.165314883)],
+        639807: [(1793957776, 1030869930, 0.240018114), (2074348501, 3545519481, 0.825505555)],
+        719393: [(556825434, 1815429807, 0.42268768), (2118670247, 2460682479, 0.572922289)],
+    }
+    for seed, rows in kat.items():
+        got = oracle.pcg_stream(seed, len(rows))
+        for (s, r, v), (gs, gr, gv) in zip(rows, got):
+            assert (s, r) == (gs, gr)
+            assert np.float32(v) == gv
+
+
+def test_pcg_against_python_integers_and_fixture(oracle):
+    fixture = json.load(open(os.path.join(GOLD, "pcg_streams.json")))
+    for seed_s, rows in fixture.items():
+        state = int(seed_s)
+        got = oracle.pcg_stream(state, len(rows))
+        for (fs, fr, fv), (gs, gr, gv) in zip(rows, got):
+            state, raw = py_pcg(state)
+            assert (state, raw) == (fs, fr) == (gs, gr)
+            # float(u) / 4294967295.0 with the literal rounded to 2^32 in fp32
+            assert np.float32(raw) * np.float32(2.0 ** -32) == gv == np.float32(fv)
+
+
+def test_random_value_reaches_one_and_zero(oracle):
+    # u >= 2^32 - 128 rounds to 2^32 when converted to fp32, so randomValue can return 1.0
+    assert np.float32(np.uint32(0xFFFFFF80)) * np.float32(2.0 ** -32) == np.float32(1.0)
+    assert np.float32(4294967295.0) == np.float32(2.0 ** 32)
+    assert np.float32(3.1415926) == np.float32(3.1415925)
+    assert np.float32(2 * np.float32(3.1415926)) == np.float32(6.283185)
+
+
+def test_default_matrices(oracle):
+    ubo = oracle.default_ubo()
+    view, proj = ubo[0:16].reshape(4, 4), ubo[16:32].reshape(4, 4)
+    assert np.array_equal(view, np.eye(4, dtype=np.float32))
+    assert proj[0, 0] == np.float32(0.75) and proj[1, 1] == np.float32(1.0)
+    assert proj[2, 3] == np.float32(1.0) and proj[3, 3] == 0.0
+    n, f = np.float32(0.01), np.float32(10000.0)
+    assert proj[2, 2] == (f + n) / (f - n)
+    assert proj[3, 2] == -(np.float32(2.0) * f * n) / (f - n)
+    assert tuple(ubo[32:34]) == (800.0, 600.0)
+    assert tuple(ubo[40:42]) == (50.0, 25.0)
+    assert tuple(ubo[60:64]) == (0.5, 0.5, 0.5, 0.5)
+    assert tuple(ubo[64:68]) == (1.0, 0.0, 0.0, 1.0)
+
+
+def test_mat4_inverse(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        m = rng.standard_normal((4, 4)).astype(np.float32)
+        inv = oracle.mat4_inverse(m.T.ravel()).reshape(4, 4).T  # column-major in and out
+        assert np.allclose(inv @ m, np.eye(4), atol=2e-4)
+
+
+def test_camera_rotation_and_view(oracle):
+    cam = oracle.camera_create(90.0, 1.0, 0.01, 10000.0)
+    oracle.camera_rotate(cam, 0.5, -0.25)
+    # yaw_sign is -1 while the camera's up vector points up; speed 0.8 (camera.cpp:15-19,62)
+    assert cam.yaw == np.float32(-1.0) * np.float32(0.5) * np.float32(0.8)
+    assert cam.pitch == np.float32(-0.25) * np.float32(0.8)
+    view = oracle.camera_view(cam).reshape(4, 4).T
+    assert np.allclose(view[:3, :3] @ view[:3, :3].T, np.eye(3), atol=1e-6)
+    assert np.allclose(view[:3, 3], 0) and np.allclose(view[3], [0, 0, 0, 1])
+    g = np.load(os.path.join(GOLD, "camera_pose.npz"))
+    cam2 = oracle.camera_create(90.0, 1.0, 0.01, 10000.0)
+    cam2.pitch, cam2.yaw = float(g["pitch"]), float(g["yaw"])
+    assert np.array_equal(oracle.camera_view(cam2).view(np.uint32), g["view"].view(np.uint32))
+    assert np.array_equal(oracle.camera_projection(cam2).view(np.uint32),
+                          g["projection"].view(np.uint32))
+
+
+def _unrle(rle, n):
+    out = np.repeat(rle[:, 0], rle[:, 1])
+    assert out.size == n
+    return out
+
+
+def test_primary_hit_census_of_the_reference_window(oracle):
+    """Default scene, 800x608 image, 800x600 viewport, jitter off: counts and landmark
+    pixels that follow from the geometry (centre pixel looks straight at sphere 0)."""
+    ubo = oracle.default_ubo()
+    ubo[40], ubo[41], ubo[66], ubo[67] = 1, 1, 0, 0
+    res = oracle.render(ubo, oracle.default_spheres(), 800, 608)
+    ids = res["ids"]
+    assert [int((ids == k).sum()) for k in (-1, 0, 1, 2)] == [257430, 11785, 13812, 203373]
+    assert ids[300, 400] == 0 and ids[0, 400] == 2
+    col = ids[:, 400]
+    assert (col[:239] == 2).all() and (col[239:362] == 0).all() and (col[362:] == -1).all()
+    assert ids[300, 799] == -1 and ids[607, 400] == -1
+    assert res["rays"] == 800 * 608
+    gold = _unrle(np.load(os.path.join(GOLD, "primary_ids_800x608_rle.npy")), 800 * 608)
+    assert np.array_equal(ids.ravel(), gold)
+
+
+def test_centre_pixel_distance_is_exactly_four(oracle):
+    """Pixel (400,300) looks down -Z at sphere 0 (centre z=-5, r=1): dst = 4.0 exactly, so
+    with an emissive sphere 0 and one bounce the pixel colour is the emission."""
+    ubo = oracle.default_ubo()
+    ubo[40], ubo[41], ubo[66], ubo[67] = 1, 1, 0, 0
+    sph = oracle.default_spheres()
+    sph[0, 8:12] = (0.25, 0.5, 1.0, 1.0)
+    res = oracle.render(ubo, sph, 800, 608)
+    assert tuple(res["accum"][300, 400, :3]) == (np.float32(0.5), np.sqrt(np.float32(0.5)), 1.0)
+    assert tuple(res["rgba8"][300, 400]) == (128, 180, 255, 255)
+
+
+def test_golden_image_fixture(oracle):
+    g = np.load(os.path.join(GOLD, "image_64x48_4spp_2frames.npz"))
+    res = oracle.render(g["ubo"], oracle.default_spheres(), 64, 48, 0, 2, 1)
+    assert res["rays"] == int(g["rays"])
+    assert np.array_equal(res["ids"], g["ids"])
+    assert np.array_equal(res["accum"].view(np.uint32), g["accum"].view(np.uint32))
+    assert np.array_equal(res["rgba8"], g["rgba8"])
+
+
+def test_threads_do_not_change_results(oracle):
+    ubo = oracle.default_ubo()
+    ubo[40] = 2
+    a = oracle.render(ubo, oracle.default_spheres(), 80, 60, threads=1)
+    b = oracle.render(ubo, oracle.default_spheres(), 80, 60, threads=7)
+    assert np.array_equal(a["accum"].view(np.uint32), b["accum"].view(np.uint32))
+    assert a["rays"] == b["rays"]
+
+
+def test_progressive_blend_in_eight_bits(oracle):
+    """ray_tracing.comp:103-109: frame 0 overwrites (weight 1); later frames blend in
+    8-bit gamma space; the image stalls once the weight drops below half a level."""
+    ubo = oracle.default_ubo()
+    ubo[40] = 1
+    one = oracle.render(ubo, oracle.default_spheres(), 40, 30, 0, 1, 1)
+    assert np.array_equal(one["rgba8"], oracle.resolve_rgba8(one["accum"]))
+    assert (one["rgba8"][..., 3] == 255).all()
+    more = oracle.render(ubo, oracle.default_spheres(), 40, 30, 1, 3, 1, accum=one["accum"].copy(),
+                         rgba8=one["rgba8"].copy())
+    full = oracle.render(ubo, oracle.default_spheres(), 40, 30, 0, 4, 1)
+    assert np.array_equal(more["rgba8"], full["rgba8"])
+    assert np.array_equal(more["accum"], full["accum"])
+    assert (full["accum"][..., 3] == 4).all()
+
+
+def test_unorm8_store_conversion(oracle):
+    L = oracle.L
+    assert L.rto_unorm8(np.nan) == 0 and L.rto_unorm8(-1.0) == 0 and L.rto_unorm8(2.0) == 255
+    assert L.rto_unorm8(0.5) == 128 and L.rto_unorm8(1.0) == 255 and L.rto_unorm8(0.0) == 0
+    assert L.rto_unorm8(1.5 / 255.0) == 2 and L.rto_unorm8(2.5 / 255.0) == 2  # ties to even
+
+
+@pytest.mark.parametrize("name,fn,lo,hi,tol_ulp", [
+    ("sin", np.sin, 0.0, 6.2832, 2.0), ("cos", np.cos, 0.0, 6.2832, 2.0),
+    ("log", np.log, 2.0 ** -32, 1.0, 2.0), ("log2", np.log2, 1e-6, 4.0, 3.0),
+    ("exp2", np.exp2, -20.0, 20.0, 2.0)])
+def test_portable_kernels_accuracy(oracle, name, fn, lo, hi, tol_ulp):
+    rng = np.random.default_rng(11)
+    x = (lo + (hi - lo) * rng.random(4000)).astype(np.float32)
+    got = oracle.pm(name, x).astype(np.float64)
+    want = fn(x.astype(np.float64))
+    if name in ("sin", "cos"):
+        assert np.max(np.abs(got - want)) < 2.5e-7          # absolute: values cross zero
+    else:
+        ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+        small = np.abs(want) < 1e-3                          # near log(1) = 0 use absolute
+        assert np.max(np.abs(got - want)[~small] / ulp[~small]) <= tol_ulp
+        assert np.max(np.abs(got - want)[small], initial=0.0) < 3e-7
+
+
+def test_portable_kernels_special_values(oracle):
+    L = oracle.L
+    assert L.rto_pm_log(0.0) == -np.inf and np.isnan(L.rto_pm_log(-1.0)) and L.rto_pm_log(1.0) == 0.0
+    assert L.rto_pm_exp2(-np.inf) == 0.0 and L.rto_pm_exp2(0.0) == 1.0 and L.rto_pm_exp2(200.0) == np.inf
+    assert L.rto_pm_exp2(10.0) == 1024.0 and L.rto_pm_exp2(-3.0) == 0.125
+    assert L.rto_pm_pow(0.0, 0.35) == 0.0 and L.rto_pm_pow(1.0, 0.35) == 1.0
+    assert np.isnan(L.rto_pm_pow(0.0, 0.0))
+    assert L.rto_pm_cos(0.0) == 1.0 and L.rto_pm_sin(0.0) == 0.0
