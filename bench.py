@@ -46,11 +46,11 @@ def algorithmic_flops(rays: float, samples: float, n_spheres: int) -> float:
 
 def cpu_baseline(ubo, spheres, threads: int):
     """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload:
-    same scene, resolution and bounce limit, 4 spp instead of 64."""
+    one full frame of the benchmark workload (all 64 spp), timed once."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as oracle
     ubo = ubo.copy()
-    spp = 4
+    spp = SPP
     ubo[40] = float(spp)
     t0 = time.perf_counter()
     res = oracle.render(ubo, spheres, WIDTH, HEIGHT, 0, 1, 1, threads=threads)
