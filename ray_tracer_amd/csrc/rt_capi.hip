@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -164,6 +165,10 @@ int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
   c->mode = cfg->mode;
   c->flags = cfg->flags;
   c->n_pixels = (size_t)cfg->width * cfg->height;
+  // wavefront mode hands the thin tail of the active queue to one drain launch; the
+  // switch point can be overridden for experiments
+  c->wf.drain_threshold = (uint32_t)(c->n_pixels / 2);
+  if (const char *e = std::getenv("RT_WF_DRAIN_THRESHOLD")) c->wf.drain_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
 
   auto bail = [&](hipError_t e, const char *what) {
     int rc = fail(RT_ERR_DEVICE, "rt_create: %s: %s", what, hipGetErrorString(e));

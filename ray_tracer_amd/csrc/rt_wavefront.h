@@ -10,6 +10,12 @@
 namespace rt {
 
 struct WavefrontState {
+  struct Impl;
+  Impl *impl = nullptr;  // path-state arrays and queues, sized for the image on first use
+  // once at most this many pixels are still active, one drain launch finishes them in
+  // registers (0: stay wavefront to the end)
+  uint32_t drain_threshold = 0;
+
   int render(bool strict, bool bvh, const Params &P, const Scene &S, const FrameSeq &F,
              const Outputs &O, hipStream_t stream, uint32_t *launches, std::string *err);
   void release();

@@ -1,9 +1,424 @@
+// Wavefront path tracer: the per-pixel program of rt_shading.h split into stages that
+// run over compacted queues, so that every wave of a stage executes one branch of the
+// shader (all "hit" or all "miss") instead of both.
+//
+// One path per pixel is in flight (a pixel's RNG state advances sequentially through
+// its samples, ray_tracing.comp:82-96, so the samples of one pixel cannot run side by
+// side).  Path state lives in HBM as structure-of-arrays of float4, indexed by pixel:
+//   P0 = origin.xyz, rng            P1 = dir.xyz, (sample << 16 | bounce)
+//   P2 = throughput.xyz, -          P3 = light.xyz, -
+//   T  = sum over samples.xyz, -    H  = (dst, sphere index) of the last extend
+//   alive = 1 while the pixel still has samples to trace in this frame
+// One iteration = two launches:
+//   extend  walks the PIXELS in order (1024 consecutive pixels per block), traces the
+//           live ones, stores H, and splits them into a hit queue and a miss queue
+//           (ballot ranks + one atomic per block and queue)
+//   shade   blocks [0, ceil(hits/1024)) scatter the hit queue, the remaining blocks
+//           light the miss queue and start the pixel's next sample
+// Queue counters rotate through four slots so no launch ever resets a counter another
+// launch of the same iteration still reads.
+//
+// Three measured facts shape the kernels.  (1) Returning atomics on ONE counter retire
+// at ~90 per microsecond chip-wide, so a push per wave (32k waves per launch at 1080p)
+// costs more than the stage's arithmetic: every thread handles kWfE entries and a block
+// reserves its output range with a single atomic per queue.  (2) A queue that is itself
+// compacted from queue order drifts into a random permutation of the pixels after a few
+// dozen iterations, and 16-byte gathers from random lines cost 3x the time of the
+// first, ordered iteration; walking pixels in order keeps every queue chunk inside a
+// 1024-pixel window of the state arrays.  (3) A few pixels need ten times more path
+// segments than the median, so the tail of the frame is hundreds of launches that do
+// almost nothing: once the live count drops below a threshold the remaining pixels are
+// compacted once and finished by one "drain" launch that keeps each path in registers
+// until its pixel is done (the megakernel's loop, resumed from the stored state).
 #include "rt_wavefront.h"
+
+#include "rt_shading.h"
+#include "rt_traverse.h"
+
 namespace rt {
-int WavefrontState::render(bool, bool, const Params &, const Scene &, const FrameSeq &, const Outputs &,
-                           hipStream_t, uint32_t *, std::string *err) {
-  if (err) *err = "wavefront mode is not available in this build";
-  return -3;
+
+struct WfView {
+  float4 *P0, *P1, *P2, *P3, *T;
+  float2 *H;
+  unsigned char *alive;
+  uint32_t *q_hit, *q_miss;
+  uint32_t *counts;  // [4 slots][4]: -, hit, miss, -; [16]: length of the drain queue
+};
+
+constexpr int kWfE = 4;                    // queue entries per thread
+constexpr uint32_t kWfChunk = 256u * kWfE;  // queue entries per block
+
+// Appends v[k] to queue q for every (lane, k) with take[k] set.  Ballots rank the lanes
+// of each wave, a 16-entry scan in LDS ranks the (k, wave) groups, and ONE atomic per
+// block reserves the output range.  Must be reached by every thread of the block.
+__device__ __forceinline__ void block_push(const bool (&take)[kWfE], const uint32_t (&v)[kWfE],
+                                           uint32_t *q, uint32_t *count, uint32_t *lds) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t rank[kWfE];
+#pragma unroll
+  for (int k = 0; k < kWfE; ++k) {
+    const unsigned long long m = __ballot(take[k]);
+    rank[k] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[k * 4 + wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < kWfE * 4; ++j) {
+      const uint32_t c = lds[j];
+      lds[j] = run;
+      run += c;
+    }
+    lds[kWfE * 4] = run ? atomicAdd(count, run) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = lds[kWfE * 4];
+#pragma unroll
+  for (int k = 0; k < kWfE; ++k)
+    if (take[k]) q[base + lds[k * 4 + wave] + rank[k]] = v[k];
+  __syncthreads();
 }
-void WavefrontState::release() {}
+
+template <bool STRICT>
+__global__ __launch_bounds__(256) void k_wf_init(Params P, uint32_t frame, WfView V) {
+  const uint32_t n = P.width * P.height;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t px = i % P.width, py = i / P.width;
+  uint32_t rng = pixel_seed(P, px, py, frame);
+  f3 o, d;
+  sample_ray<STRICT>(P, pixel_direction(P, px, py), rng, o, d);
+  V.P0[i] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+  V.P1[i] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));
+  V.P2[i] = make_float4(1.f, 1.f, 1.f, 0.f);
+  V.P3[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  V.T[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  V.alive[i] = 1;
+}
+
+template <bool BVH>
+__global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t slot, uint32_t n_pixels,
+                                                   int32_t *ids) {
+  __shared__ uint32_t lds[kWfE * 4 + 1];
+  uint32_t *cnt = V.counts + 4u * (slot & 3u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t *z = V.counts + 4u * ((slot + 1u) & 3u);
+    z[1] = 0u;
+    z[2] = 0u;
+  }
+  const uint32_t first = blockIdx.x * kWfChunk;
+  bool is_hit[kWfE], is_miss[kWfE];
+  uint32_t pix[kWfE];
+#pragma unroll
+  for (int k = 0; k < kWfE; ++k) {
+    pix[k] = first + (uint32_t)k * 256u + threadIdx.x;
+    is_hit[k] = is_miss[k] = false;
+    if (pix[k] < n_pixels && V.alive[pix[k]]) {
+      const float4 p0 = V.P0[pix[k]], p1 = V.P1[pix[k]];
+      Hit h;
+      if constexpr (BVH) h = closest_hit_bvh(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z));
+      else h = closest_hit_brute(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z));
+      V.H[pix[k]] = make_float2(h.dst, __int_as_float(h.idx));
+      if (__float_as_uint(p1.w) == 0u) ids[pix[k]] = h.idx;  // sample 0, bounce 0
+      is_hit[k] = h.idx >= 0;
+      is_miss[k] = !is_hit[k];
+    }
+  }
+  block_push(is_hit, pix, V.q_hit, cnt + 1, lds);
+  block_push(is_miss, pix, V.q_miss, cnt + 2, lds);
+}
+
+// A path ended with radiance `light`: fold it into the pixel's sample sum and either
+// start the next sample (returns true, state written) or finish the pixel's frame.
+template <bool STRICT>
+__device__ __forceinline__ bool path_end(const Params &P, const WfView &V, const Outputs &O,
+                                         uint32_t frame, uint32_t pix, uint32_t rng, uint32_t s,
+                                         f3 light) {
+  float4 t = V.T[pix];
+  f3 total = mk3(t.x, t.y, t.z) + light;
+  ++s;
+  if (s >= (uint32_t)P.n_spp) {
+    float4 acc = O.accum[pix];
+    uchar4 img = O.rgba8[pix];
+    frame_epilogue(P, total, (float)frame, O.linear_accum, acc, img);
+    O.accum[pix] = acc;
+    O.rgba8[pix] = img;
+    V.alive[pix] = 0;
+    return false;
+  }
+  V.T[pix] = make_float4(total.x, total.y, total.z, 0.f);
+  const uint32_t px = pix % P.width, py = pix / P.width;
+  f3 o, d;
+  sample_ray<STRICT>(P, pixel_direction(P, px, py), rng, o, d);
+  V.P0[pix] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+  V.P1[pix] = make_float4(d.x, d.y, d.z, __uint_as_float(s << 16));
+  V.P2[pix] = make_float4(1.f, 1.f, 1.f, 0.f);
+  V.P3[pix] = make_float4(0.f, 0.f, 0.f, 0.f);
+  return true;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, uint32_t slot,
+                                                  uint32_t frame, Outputs O) {
+  const uint32_t *cnt = V.counts + 4u * (slot & 3u);
+  const uint32_t n_hit = cnt[1], n_miss = cnt[2];
+  const uint32_t hit_blocks = (n_hit + kWfChunk - 1u) / kWfChunk;
+  const uint32_t miss_blocks = (n_miss + kWfChunk - 1u) / kWfChunk;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (n_hit + n_miss))
+    atomicAdd(O.rays, (unsigned long long)(n_hit + n_miss));
+  if (blockIdx.x >= hit_blocks + miss_blocks) return;
+  if (blockIdx.x < hit_blocks) {
+#pragma unroll
+    for (int k = 0; k < kWfE; ++k) {
+      const uint32_t qi = blockIdx.x * kWfChunk + (uint32_t)k * 256u + threadIdx.x;
+      if (qi < n_hit) {
+        const uint32_t px = V.q_hit[qi];
+        const float4 p0 = V.P0[px], p1 = V.P1[px], p2 = V.P2[px], p3 = V.P3[px];
+        const float2 hrec = V.H[px];
+        const int idx = __float_as_int(hrec.y);
+        uint32_t rng = __float_as_uint(p0.w);
+        const uint32_t sb = __float_as_uint(p1.w);
+        uint32_t s = sb >> 16, b = sb & 0xffffu;
+        f3 o = mk3(p0.x, p0.y, p0.z), d = mk3(p1.x, p1.y, p1.z);
+        f3 colour = mk3(p2.x, p2.y, p2.z), light = mk3(p3.x, p3.y, p3.z);
+        const float4 g = S.geom[idx];
+        scatter<STRICT>(mk3(g.x, g.y, g.z), S.material[3 * idx], S.material[3 * idx + 1],
+                        S.material[3 * idx + 2], hrec.x, rng, o, d, light, colour);
+        ++b;
+        if (b >= (uint32_t)P.n_bounce) {
+          path_end<STRICT>(P, V, O, frame, px, rng, s, light);
+        } else {
+          V.P0[px] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+          V.P1[px] = make_float4(d.x, d.y, d.z, __uint_as_float((s << 16) | b));
+          V.P2[px] = make_float4(colour.x, colour.y, colour.z, 0.f);
+          V.P3[px] = make_float4(light.x, light.y, light.z, 0.f);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kWfE; ++k) {
+      const uint32_t qi = (blockIdx.x - hit_blocks) * kWfChunk + (uint32_t)k * 256u + threadIdx.x;
+      if (qi < n_miss) {
+        const uint32_t px = V.q_miss[qi];
+        const float4 p0 = V.P0[px], p1 = V.P1[px], p2 = V.P2[px], p3 = V.P3[px];
+        f3 light = fma3v(environment<STRICT>(P, mk3(p1.x, p1.y, p1.z)), mk3(p2.x, p2.y, p2.z),
+                         mk3(p3.x, p3.y, p3.z));
+        path_end<STRICT>(P, V, O, frame, px, __float_as_uint(p0.w), __float_as_uint(p1.w) >> 16,
+                         light);
+      }
+    }
+  }
+}
+
+// Gathers the pixels that are still alive into the drain queue (q_hit, counts[16]).
+__global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels) {
+  __shared__ uint32_t lds[kWfE * 4 + 1];
+  const uint32_t first = blockIdx.x * kWfChunk;
+  bool take[kWfE];
+  uint32_t pix[kWfE];
+#pragma unroll
+  for (int k = 0; k < kWfE; ++k) {
+    pix[k] = first + (uint32_t)k * 256u + threadIdx.x;
+    take[k] = pix[k] < n_pixels && V.alive[pix[k]] != 0;
+  }
+  block_push(take, pix, V.q_hit, V.counts + 16, lds);
+}
+
+// Finishes every pixel of the drain queue in registers: the loop of the regenerating
+// megakernel, resumed from the stored path state, for this one frame.
+template <bool STRICT, bool BVH>
+__global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, uint32_t frame,
+                                                  Outputs O) {
+  const uint32_t n = V.counts[16];
+  const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
+  uint32_t nrays = 0;
+  if (qi < n) {
+    const uint32_t pix = V.q_hit[qi];
+    const float4 p0 = V.P0[pix], p1 = V.P1[pix], p2 = V.P2[pix], p3 = V.P3[pix], t = V.T[pix];
+    const uint32_t px = pix % P.width, py = pix / P.width;
+    const f3 base = pixel_direction(P, px, py);
+    uint32_t rng = __float_as_uint(p0.w);
+    const uint32_t sb = __float_as_uint(p1.w);
+    int s = (int)(sb >> 16), b = (int)(sb & 0xffffu);
+    f3 o = mk3(p0.x, p0.y, p0.z), d = mk3(p1.x, p1.y, p1.z);
+    f3 colour = mk3(p2.x, p2.y, p2.z), light = mk3(p3.x, p3.y, p3.z);
+    f3 total = mk3(t.x, t.y, t.z);
+    int id0 = -2;
+    while (true) {
+      Hit h;
+      if constexpr (BVH) h = closest_hit_bvh(S, o, d);
+      else h = closest_hit_brute(S, o, d);
+      ++nrays;
+      if (s == 0 && b == 0) id0 = h.idx;
+      bool path_done;
+      if (h.idx >= 0) {
+        const float4 g = S.geom[h.idx];
+        scatter<STRICT>(mk3(g.x, g.y, g.z), S.material[3 * h.idx], S.material[3 * h.idx + 1],
+                        S.material[3 * h.idx + 2], h.dst, rng, o, d, light, colour);
+        ++b;
+        path_done = b >= P.n_bounce;
+      } else {
+        light = fma3v(environment<STRICT>(P, d), colour, light);
+        path_done = true;
+      }
+      if (path_done) {
+        total = total + light;
+        ++s;
+        if (s >= P.n_spp) break;
+        sample_ray<STRICT>(P, base, rng, o, d);
+        light = mk3(0.f, 0.f, 0.f);
+        colour = mk3(1.f, 1.f, 1.f);
+        b = 0;
+      }
+    }
+    float4 acc = O.accum[pix];
+    uchar4 img = O.rgba8[pix];
+    frame_epilogue(P, total, (float)frame, O.linear_accum, acc, img);
+    O.accum[pix] = acc;
+    O.rgba8[pix] = img;
+    if (id0 != -2) O.ids[pix] = id0;
+  }
+  const uint32_t wsum = wave_sum_u32(nrays);
+  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+}
+
+// ---- host side ---------------------------------------------------------------------
+struct WavefrontState::Impl {
+  size_t n_pixels = 0;
+  char *slab = nullptr;       // one allocation carved into the arrays below
+  WfView view{};
+  uint32_t *h_counts = nullptr;  // pinned read-back ring
+  hipEvent_t ev[8] = {};
+};
+
+static constexpr int kCheckEvery = 4;   // iterations between read-backs of the active count
+static constexpr int kReadbackLag = 1;  // read-backs the host may run ahead of the device
+
+void WavefrontState::release() {
+  if (!impl) return;
+  if (impl->slab) hipFree(impl->slab);
+  if (impl->h_counts) hipHostFree(impl->h_counts);
+  for (auto &e : impl->ev)
+    if (e) hipEventDestroy(e);
+  delete impl;
+  impl = nullptr;
+}
+
+#define WF_HIP(call)                                                          \
+  do {                                                                        \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      if (err) *err = std::string(#call) + ": " + hipGetErrorString(e_);      \
+      return -2;                                                              \
+    }                                                                         \
+  } while (0)
+
+static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) {
+  if (impl && impl->n_pixels == n) return 0;
+  if (impl) {
+    if (impl->slab) hipFree(impl->slab);
+    impl->slab = nullptr;
+  } else {
+    impl = new WavefrontState::Impl();
+    WF_HIP(hipHostMalloc((void **)&impl->h_counts, 16 * sizeof(uint32_t)));
+    for (auto &e : impl->ev) WF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const size_t f4 = n * sizeof(float4), q = ((n * sizeof(uint32_t) + 255) / 256) * 256;
+  const size_t h = ((n * sizeof(float2) + 255) / 256) * 256;
+  const size_t a = ((n + 255) / 256) * 256;
+  const size_t total = 5 * f4 + h + 2 * q + a + 256;
+  WF_HIP(hipMalloc((void **)&impl->slab, total));
+  char *p = impl->slab;
+  WfView &V = impl->view;
+  V.P0 = (float4 *)p; p += f4;
+  V.P1 = (float4 *)p; p += f4;
+  V.P2 = (float4 *)p; p += f4;
+  V.P3 = (float4 *)p; p += f4;
+  V.T = (float4 *)p; p += f4;
+  V.H = (float2 *)p; p += h;
+  V.alive = (unsigned char *)p; p += a;
+  V.q_hit = (uint32_t *)p; p += q;
+  V.q_miss = (uint32_t *)p; p += q;
+  V.counts = (uint32_t *)p;
+  impl->n_pixels = n;
+  return 0;
+}
+
+template <bool STRICT, bool BVH>
+static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const Params &P,
+                    const Scene &S, uint32_t frame, const Outputs &O, hipStream_t stream,
+                    uint32_t *launches, std::string *err) {
+  const WfView &V = impl->view;
+  const uint32_t n = (uint32_t)impl->n_pixels;
+  const uint32_t full_blocks = (n + 255u) / 256u;
+  const uint32_t window_blocks = (n + kWfChunk - 1u) / kWfChunk;
+  WF_HIP(hipMemsetAsync(V.counts, 0, 128, stream));
+  hipLaunchKernelGGL((k_wf_init<STRICT>), dim3(full_blocks), dim3(256), 0, stream, P, frame, V);
+  ++*launches;
+  uint32_t bound = n;  // upper bound of the live-pixel count (it never grows within a frame)
+  // worst case: every sample of the slowest pixel runs to the bounce limit
+  const uint64_t max_iters = (uint64_t)P.n_spp * (uint64_t)P.n_bounce;
+  int pending = 0;     // read-backs issued and not yet consumed
+  uint32_t issue = 0, consume = 0;
+  for (uint64_t it = 0; it < max_iters; ++it) {
+    const uint32_t slot = (uint32_t)(it & 3u);
+    if (bound <= drain_threshold) {
+      hipLaunchKernelGGL(k_wf_compact, dim3(window_blocks), dim3(256), 0, stream, V, n);
+      hipLaunchKernelGGL((k_wf_drain<STRICT, BVH>), dim3((bound + 255u) / 256u), dim3(256), 0, stream,
+                         P, S, V, frame, O);
+      *launches += 2;
+      break;
+    }
+    hipLaunchKernelGGL((k_wf_extend<BVH>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+                       O.ids);
+    hipLaunchKernelGGL((k_wf_shade<STRICT>), dim3((bound + kWfChunk - 1u) / kWfChunk + 1u), dim3(256),
+                       0, stream, P, S, V, slot, frame, O);
+    *launches += 2;
+    if ((it + 1) % kCheckEvery == 0) {
+      // hit and miss counts of this iteration (their sum = live pixels) -> pinned ring,
+      // consumed one read-back later so the host runs ahead of the device
+      const uint32_t r = issue++ & 7u;
+      WF_HIP(hipMemcpyAsync(&impl->h_counts[2 * r], V.counts + 4u * slot + 1u, 2 * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, stream));
+      WF_HIP(hipEventRecord(impl->ev[r], stream));
+      ++pending;
+      if (pending > kReadbackLag) {
+        const uint32_t c = consume++ & 7u;
+        WF_HIP(hipEventSynchronize(impl->ev[c]));
+        --pending;
+        const uint32_t live = impl->h_counts[2 * c] + impl->h_counts[2 * c + 1];
+        if (live == 0u) break;
+        if (live < bound) bound = live;
+      }
+    }
+  }
+  WF_HIP(hipGetLastError());
+  return 0;
+}
+
+int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &S, const FrameSeq &F,
+                           const Outputs &O, hipStream_t stream, uint32_t *launches,
+                           std::string *err) {
+  if (P.n_spp > 65535 || P.n_bounce > 65535) {
+    if (err) *err = "wavefront mode packs sample and bounce counters into 16 bits each";
+    return -1;
+  }
+  int rc = wf_allocate(impl, (size_t)P.width * P.height, err);
+  if (rc) return rc;
+  *launches = 0;
+  for (uint32_t fi = 0; fi < F.count; ++fi) {
+    const uint32_t frame = F.first + fi * F.stride;
+    if (strict)
+      rc = bvh ? wf_frame<true, true>(impl, drain_threshold, P, S, frame, O, stream, launches, err)
+               : wf_frame<true, false>(impl, drain_threshold, P, S, frame, O, stream, launches, err);
+    else
+      rc = bvh ? wf_frame<false, true>(impl, drain_threshold, P, S, frame, O, stream, launches, err)
+               : wf_frame<false, false>(impl, drain_threshold, P, S, frame, O, stream, launches, err);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 }  // namespace rt

@@ -1,18 +1,14 @@
-import time, numpy as np, sys
+import time, numpy as np, sys, os
 sys.path.insert(0, '.')
 import ray_tracer_amd as rt
 w,h,spp=1920,1080,64
 ubo = rt.make_ubo(w,h,spp,25); sph = rt.default_scene()
-for mode,name in ((rt.MODE_MEGAKERNEL,'regen'),(rt.MODE_MEGAKERNEL_NESTED,'nested')):
-  for flags,fn in ((0,'fast'),(rt.FLAG_STRICT_MATH,'strict')):
-    with rt.Renderer(w,h,mode=mode,flags=flags) as r:
+for thr in (0, 2000, 65536, 262144, 524288, 1048576):
+    os.environ['RT_WF_DRAIN_THRESHOLD']=str(thr)
+    with rt.Renderer(w,h,mode=rt.MODE_WAVEFRONT,flags=0) as r:
         r.set_params(ubo); r.set_spheres(sph)
         r.render(0,1,1); r.sync()
-        st0 = r.stats()
-        for k in range(3):
-            r.render(1+k,1,1)
+        for k in range(2):
+            t0=time.perf_counter(); r.render(1+k,1,1); r.sync(); t1=time.perf_counter()
             st = r.stats()
-            print(name, fn, 'ms', st.last_render_ms, 'rays', st.rays, flush=True)
-        st = r.stats()
-        rays_per_frame = st.rays/4
-        print(name, fn, 'Grays/s', rays_per_frame/ (st.last_render_ms*1e-3)/1e9, flush=True)
+            print('wavefront thr', thr, 'ms', st.last_render_ms, 'wall ms', (t1-t0)*1e3, 'rays', st.rays, 'launches', st.last_launches, flush=True)
