@@ -72,7 +72,7 @@ typedef struct rt_stats {
   uint32_t last_launches;   /* kernel launches issued by the last rt_render */
   uint32_t bvh_nodes;       /* internal nodes of the current LBVH, 0 when brute force */
   float last_build_ms;      /* device time of the last LBVH build */
-  uint32_t reserved;
+  uint32_t bvh_height;      /* longest root-to-leaf path of the LBVH, in edges */
 } rt_stats;
 
 /* Replaces createTexture(RGBA8_UNORM, W, H, STORAGE) + zero fill, main.cpp:393-448,

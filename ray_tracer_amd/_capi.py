@@ -102,7 +102,7 @@ class _Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("last_render_ms", C.c_float),
                 ("total_render_ms", C.c_float), ("last_launches", C.c_uint32),
-                ("bvh_nodes", C.c_uint32), ("last_build_ms", C.c_float), ("reserved", C.c_uint32)]
+                ("bvh_nodes", C.c_uint32), ("last_build_ms", C.c_float), ("bvh_height", C.c_uint32)]
 
 
 lib.rt_last_error.restype = C.c_char_p

@@ -65,6 +65,7 @@ struct rt_ctx {
 
   rt::Lbvh bvh;                  // device LBVH + build workspace
   bool use_bvh = false;
+  float bvh_cam[3] = {0.f, 0.f, 0.f};  // camera position the leaf boxes were sized for
 
   rt::WavefrontState wf;         // queues of the wavefront pipeline
 
@@ -267,6 +268,16 @@ int rt_set_params(rt_ctx *c, const void *ubo272) {
   P.rcp_w = 1.0f / P.fwidth;
   P.rcp_h = 1.0f / P.fheight;
   c->have_params = true;
+  if (c->use_bvh && (P.cam_x != c->bvh_cam[0] || P.cam_y != c->bvh_cam[1] || P.cam_z != c->bvh_cam[2])) {
+    // leaf boxes are sized from the distance to the camera: rebuild for the new position
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    std::string err;
+    const float cam[3] = {P.cam_x, P.cam_y, P.cam_z};
+    int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), c->n_spheres, cam, c->stream, &err);
+    if (rc != RT_OK) return fail(rc, "rt_set_params: LBVH rebuild: %s", err.c_str());
+    std::memcpy(c->bvh_cam, cam, sizeof cam);
+  }
   return RT_OK;
 }
 
@@ -307,8 +318,14 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
                   (!(c->flags & RT_FLAG_FORCE_BRUTE) && count > 16u);
   if (want_bvh && count >= 1) {
     std::string err;
-    int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), count, c->stream, &err);
+    const float cam[3] = {c->have_params ? c->P.cam_x : 0.f, c->have_params ? c->P.cam_y : 0.f,
+                          c->have_params ? c->P.cam_z : 0.f};
+    int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), count, cam, c->stream, &err);
     if (rc != RT_OK) return fail(rc, "rt_set_spheres: LBVH build: %s", err.c_str());
+    if (c->bvh.height > (uint32_t)rt::kBvhStackEntries)
+      return fail(RT_ERR_INVALID, "rt_set_spheres: LBVH height %u exceeds the traversal stack (%d)",
+                  c->bvh.height, rt::kBvhStackEntries);
+    std::memcpy(c->bvh_cam, cam, sizeof cam);
     c->use_bvh = true;
   }
   c->have_scene = true;
@@ -420,6 +437,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
   out->last_launches = c->last_launches;
   out->bvh_nodes = c->use_bvh ? c->bvh.n_nodes : 0u;
   out->last_build_ms = c->bvh.last_build_ms;
+  out->bvh_height = c->use_bvh ? c->bvh.height : 0u;
   return RT_OK;
 }
 

@@ -42,6 +42,8 @@ struct BvhNode {
   int32_t count1;
 };
 
+constexpr int kBvhStackEntries = 32;  // traversal stack entries per lane (>= tree height)
+
 struct Scene {
   const float4 *geom;       // per sphere: centre.xyz, radius*radius   (original order)
   const float4 *material;   // per sphere: colour, emission, specular  (3 x float4)

@@ -4,20 +4,31 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "rt_device_scene.h"
 
 namespace rt {
 
 struct Lbvh {
-  BvhNode *nodes = nullptr;
-  uint32_t *sorted_prim = nullptr;
-  float4 *sorted_geom = nullptr;
+  // device arrays read by traversal
+  BvhNode *nodes = nullptr;        // n-1 internal nodes, root = 0
+  uint32_t *sorted_prim = nullptr; // leaf position -> original sphere index
+  float4 *sorted_geom = nullptr;   // (centre, r*r) in leaf order
   uint32_t n_nodes = 0;
+  uint32_t capacity = 0;           // spheres the arrays above can hold
+  uint32_t height = 0;             // longest root-to-leaf path in edges = traversal stack bound
+  uint32_t refit_passes = 0;
   float last_build_ms = 0.f;
 
-  int build(const float4 *d_geom, const float *h_spheres64, uint32_t n, hipStream_t stream,
-            std::string *err);
+  struct Work;
+  Work *work = nullptr;            // build workspace, kept between builds
+
+  // d_geom: device (centre, r*r) per sphere; h_spheres64: the 64-byte host records;
+  // cam: camera position (ray origins are assumed to stay near the camera and the spheres).
+  int build(const float4 *d_geom, const float *h_spheres64, uint32_t n, const float cam[3],
+            hipStream_t stream, std::string *err);
+  int download(std::vector<BvhNode> *out_nodes, std::vector<uint32_t> *out_prims) const;
   void release();
 };
 

@@ -1,8 +1,545 @@
+// Linear BVH over spheres, built on the GPU.
+//
+//   1. leaf boxes (inflated, see below) + bounds of the centres       k_leaf_boxes
+//   2. 30-bit Morton code of each centre                              k_morton
+//   3. stable LSD radix sort of (code, index), 4 passes of 8 bits     k_rs_hist / k_rs_scan / k_rs_scatter
+//   4. Karras (2012) radix-tree hierarchy over the sorted codes,      k_hierarchy
+//      ties broken by sorted position
+//   5. bottom-up bounds, level-synchronous across launches            k_refit
+//   6. nodes with both child boxes inline (one 64-byte fetch per      (written by k_refit)
+//      traversal step), geometry permuted into leaf order             k_permute
+//
+// Why the leaf boxes are inflated.  The closest-hit search must return exactly what the
+// shader's brute-force loop returns, and that loop runs the quadratic in fp32: for a ray
+// whose origin is |oc| away from a sphere of radius r the discriminant carries an
+// absolute error of a few ulp of |oc|^2, so the float test reports hits for rays that
+// pass up to ~3 eps |oc|^2 / r OUTSIDE the sphere.  A tight box would cull those.  Each
+// leaf box is therefore grown by r * alpha with alpha = 4.8e-7 * D^2 / r^2, where D bounds
+// the distance from the sphere to any ray origin (camera and the region the ordinary-
+// sized spheres occupy), clamped to [2^-10, 0.5].
+//
+// Refit without intra-launch hand-offs.  A node may be finished in pass p only from
+// children that were finished in an EARLIER launch (their stamp is non-zero and < p), so
+// every value it reads crossed a kernel boundary; a thread that finishes a node climbs
+// to the parent right away when the sibling is such an earlier node.  No fences, no
+// dependence on dispatch order or on which XCD a block runs.
 #include "rt_lbvh.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
 namespace rt {
-int Lbvh::build(const float4 *, const float *, uint32_t, hipStream_t, std::string *err) {
-  if (err) *err = "LBVH build is not available in this build";
-  return -3;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRsE = 8;                         // keys per thread per radix pass
+constexpr uint32_t kRsTile = kThreads * kRsE;   // keys per block
+
+struct BoxParams {
+  float blo[3], bhi[3];  // region ray origins are assumed to stay in
+};
+
+// order-preserving map float -> uint for atomicMin / atomicMax
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-void Lbvh::release() {}
+__host__ __device__ inline float ord2f(uint32_t u) {
+  uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(b);
+#else
+  std::memcpy(&f, &b, 4);
+#endif
+  return f;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// cr = centre.xyz, radius.  cbounds = 6 ordered words: min xyz, max xyz of the centres.
+__global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restrict__ cr, uint32_t n,
+                                                         BoxParams bp, float4 *__restrict__ leaf_lo,
+                                                         float4 *__restrict__ leaf_hi,
+                                                         uint32_t *cbounds) {
+  float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    const float4 s = cr[i];
+    const float c[3] = {s.x, s.y, s.z};
+    float d2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float far = fmaxf(fabsf(c[k] - bp.blo[k]), fabsf(c[k] - bp.bhi[k]));
+      d2 += far * far;
+      mn[k] = fminf(mn[k], c[k]);
+      mx[k] = fmaxf(mx[k], c[k]);
+    }
+    const float r = fabsf(s.w);
+    float alpha = 4.8e-7f * d2 / fmaxf(r * r, 1e-30f);
+    alpha = fminf(fmaxf(alpha, 0x1p-10f), 0.5f);
+    const float h = r + r * alpha + 1e-30f;
+    leaf_lo[i] = make_float4(c[0] - h, c[1] - h, c[2] - h, 0.f);
+    leaf_hi[i] = make_float4(c[0] + h, c[1] + h, c[2] + h, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&cbounds[k], f2ord(a));
+      atomicMax(&cbounds[3 + k], f2ord(b));
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_morton(const float4 *__restrict__ cr, uint32_t n,
+                                                     const uint32_t *__restrict__ cbounds,
+                                                     uint32_t *__restrict__ keys,
+                                                     uint32_t *__restrict__ vals) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const float4 s = cr[i];
+  const float c[3] = {s.x, s.y, s.z};
+  uint32_t q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lo = ord2f(cbounds[k]), hi = ord2f(cbounds[3 + k]);
+    const float ext = hi - lo;
+    float t = ext > 0.f ? (c[k] - lo) / ext : 0.f;
+    t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
+    q[k] = (uint32_t)t;
+  }
+  keys[i] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+  vals[i] = i;
+}
+
+// ---- radix sort, one 8-bit digit per pass ---------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_rs_hist(const uint32_t *__restrict__ keys, uint32_t n,
+                                                      uint32_t shift, uint32_t *__restrict__ hist,
+                                                      uint32_t nblk) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t first = blockIdx.x * kRsTile;
+#pragma unroll
+  for (int k = 0; k < kRsE; ++k) {
+    const uint32_t i = first + k * kThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];  // digit-major: scan order
+}
+
+// exclusive scan of `total` counters in place, one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *data, uint32_t total) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (total + 1023u) / 1024u;
+  const uint32_t b = threadIdx.x * per, e = min(b + per, total);
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; ++i) sum += data[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024u; off <<= 1) {
+    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
+  for (uint32_t i = b; i < e; ++i) {
+    const uint32_t c = data[i];
+    data[i] = run;
+    run += c;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
+                                                         const uint32_t *__restrict__ vals_in,
+                                                         uint32_t *__restrict__ keys_out,
+                                                         uint32_t *__restrict__ vals_out, uint32_t n,
+                                                         uint32_t shift,
+                                                         const uint32_t *__restrict__ hist,
+                                                         uint32_t nblk) {
+  __shared__ uint32_t base[256];       // next output slot of each digit for this block
+  __shared__ uint32_t wcount[4][256];  // per wave, keys of each digit in the current round
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  base[t] = hist[t * nblk + blockIdx.x];
+  const uint32_t first = blockIdx.x * kRsTile;
+  for (int k = 0; k < kRsE; ++k) {
+    wcount[0][t] = 0; wcount[1][t] = 0; wcount[2][t] = 0; wcount[3][t] = 0;
+    __syncthreads();
+    const uint32_t i = first + k * kThreads + t;
+    const bool valid = i < n;
+    const uint32_t key = valid ? keys_in[i] : 0xffffffffu;
+    const uint32_t val = valid ? vals_in[i] : 0u;
+    const uint32_t digit = (key >> shift) & 255u;
+    // lanes of this wave holding the same digit (stable: rank = lower lanes first)
+    unsigned long long mask = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (digit >> b) & 1u;
+      const unsigned long long bm = __ballot(bit);
+      mask &= bit ? bm : ~bm;
+    }
+    const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+    const uint32_t rank = __popcll(lower);
+    if (valid && lower == 0ull) wcount[wave][digit] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (valid) {
+      uint32_t off = base[digit];
+      for (uint32_t w = 0; w < wave; ++w) off += wcount[w][digit];
+      keys_out[off + rank] = key;
+      vals_out[off + rank] = val;
+    }
+    __syncthreads();
+    base[t] += wcount[0][t] + wcount[1][t] + wcount[2][t] + wcount[3][t];
+    __syncthreads();
+  }
+}
+
+// ---- hierarchy (Karras 2012) ------------------------------------------------------------
+// common-prefix length of sorted keys i and j; equal codes fall back to the position
+__device__ __forceinline__ int delta(const uint32_t *__restrict__ codes, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint32_t a = codes[i], b = codes[j];
+  if (a != b) return __clz(a ^ b);
+  return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+}
+
+// child encoding: >= 0 internal node index, < 0 leaf at sorted position ~child
+__global__ __launch_bounds__(kThreads) void k_hierarchy(const uint32_t *__restrict__ codes, int n,
+                                                        int *__restrict__ left, int *__restrict__ right,
+                                                        int *__restrict__ parent,
+                                                        int *__restrict__ leaf_parent) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n - 1) return;
+  if (i == 0) parent[0] = -1;
+  const int d = (delta(codes, n, i, i + 1) - delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(codes, n, i, i - d);
+  int lmax = 2;
+  while (delta(codes, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(codes, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(codes, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(codes, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  const int lc = (lo == gamma) ? ~gamma : gamma;
+  const int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+  left[i] = lc;
+  right[i] = rc;
+  if (lc < 0) leaf_parent[gamma] = i; else parent[lc] = i;
+  if (rc < 0) leaf_parent[gamma + 1] = i; else parent[rc] = i;
+}
+
+struct RefitView {
+  const int *left, *right, *parent;
+  const uint32_t *sorted_prim;        // sorted position -> original index
+  const float4 *leaf_lo, *leaf_hi;    // by original index
+  uint32_t *stamp;                    // pass in which a node was finished, 0 = not yet
+  float4 *box_lo, *box_hi;            // bounds of finished nodes; .w of box_lo = subtree height
+  BvhNode *nodes;
+  int n_internal;
+};
+
+__device__ __forceinline__ bool child_ready(const RefitView &v, int c, uint32_t pass) {
+  if (c < 0) return true;
+  const uint32_t s = v.stamp[c];
+  return s != 0u && s < pass;
+}
+__device__ __forceinline__ void child_box(const RefitView &v, int c, float4 &lo, float4 &hi,
+                                          float &height) {
+  if (c < 0) {
+    const uint32_t prim = v.sorted_prim[~c];
+    lo = v.leaf_lo[prim];
+    hi = v.leaf_hi[prim];
+    height = 0.f;
+  } else {
+    lo = v.box_lo[c];
+    hi = v.box_hi[c];
+    height = lo.w;
+  }
+}
+// writes node i from its two children's boxes; returns its own box in (lo, hi, height)
+__device__ __forceinline__ void finish_node(const RefitView &v, int i, int c0, int c1, float4 l0,
+                                            float4 h0, float ht0, float4 l1, float4 h1, float ht1,
+                                            uint32_t pass, float4 &lo, float4 &hi, float &height) {
+  BvhNode nd;
+  nd.lo0[0] = l0.x; nd.lo0[1] = l0.y; nd.lo0[2] = l0.z; nd.child0 = c0;
+  nd.hi0[0] = h0.x; nd.hi0[1] = h0.y; nd.hi0[2] = h0.z; nd.count0 = 0;
+  nd.lo1[0] = l1.x; nd.lo1[1] = l1.y; nd.lo1[2] = l1.z; nd.child1 = c1;
+  nd.hi1[0] = h1.x; nd.hi1[1] = h1.y; nd.hi1[2] = h1.z; nd.count1 = 0;
+  v.nodes[i] = nd;
+  height = fmaxf(ht0, ht1) + 1.f;
+  lo = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), height);
+  hi = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.f);
+  v.box_lo[i] = lo;
+  v.box_hi[i] = hi;
+  v.stamp[i] = pass;
+}
+
+__global__ __launch_bounds__(kThreads) void k_refit(RefitView v, uint32_t pass) {
+  int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= v.n_internal || v.stamp[i] != 0u) return;
+  const int c0 = v.left[i], c1 = v.right[i];
+  if (!child_ready(v, c0, pass) || !child_ready(v, c1, pass)) return;
+  float4 l0, h0, l1, h1, lo, hi;
+  float ht0, ht1, height;
+  child_box(v, c0, l0, h0, ht0);
+  child_box(v, c1, l1, h1, ht1);
+  finish_node(v, i, c0, c1, l0, h0, ht0, l1, h1, ht1, pass, lo, hi, height);
+  // climb while the sibling was finished by an earlier launch
+  for (;;) {
+    const int p = v.parent[i];
+    if (p < 0) break;
+    const int pc0 = v.left[p], pc1 = v.right[p];
+    const bool i_is_left = (pc0 == i);
+    const int sib = i_is_left ? pc1 : pc0;
+    if (!child_ready(v, sib, pass)) break;
+    float4 sl, sh;
+    float sht;
+    child_box(v, sib, sl, sh, sht);
+    float4 nlo, nhi;
+    float nh;
+    if (i_is_left) finish_node(v, p, pc0, pc1, lo, hi, height, sl, sh, sht, pass, nlo, nhi, nh);
+    else finish_node(v, p, pc0, pc1, sl, sh, sht, lo, hi, height, pass, nlo, nhi, nh);
+    lo = nlo; hi = nhi; height = nh;
+    i = p;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_permute(const float4 *__restrict__ geom,
+                                                      const uint32_t *__restrict__ sorted_prim,
+                                                      float4 *__restrict__ sorted_geom, uint32_t n) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) sorted_geom[i] = geom[sorted_prim[i]];
+}
+
+}  // namespace
+
+struct Lbvh::Work {
+  size_t capacity = 0;
+  char *slab = nullptr;
+  float4 *cr = nullptr, *leaf_lo = nullptr, *leaf_hi = nullptr, *box_lo = nullptr, *box_hi = nullptr;
+  uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr};
+  uint32_t *hist = nullptr, *stamp = nullptr, *cbounds = nullptr;
+  int *left = nullptr, *right = nullptr, *parent = nullptr, *leaf_parent = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+void Lbvh::release() {
+  if (work) {
+    if (work->slab) hipFree(work->slab);
+    if (work->ev0) hipEventDestroy(work->ev0);
+    if (work->ev1) hipEventDestroy(work->ev1);
+    delete work;
+    work = nullptr;
+  }
+  if (nodes) hipFree(nodes);
+  if (sorted_prim) hipFree(sorted_prim);
+  if (sorted_geom) hipFree(sorted_geom);
+  nodes = nullptr;
+  sorted_prim = nullptr;
+  sorted_geom = nullptr;
+  n_nodes = 0;
+  capacity = 0;
+}
+
+#define BVH_HIP(call)                                                       \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) {                                                 \
+      if (err) *err = std::string(#call) + ": " + hipGetErrorString(e_);    \
+      return -2;                                                            \
+    }                                                                       \
+  } while (0)
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, const float cam[3],
+                hipStream_t stream, std::string *err) {
+  if (n == 0) {
+    if (err) *err = "empty scene";
+    return -1;
+  }
+  // ---- storage -----------------------------------------------------------------------
+  if (n > capacity) {
+    if (nodes) hipFree(nodes);
+    if (sorted_prim) hipFree(sorted_prim);
+    if (sorted_geom) hipFree(sorted_geom);
+    nodes = nullptr; sorted_prim = nullptr; sorted_geom = nullptr;
+    BVH_HIP(hipMalloc((void **)&nodes, (size_t)std::max(n - 1, 1u) * sizeof(BvhNode)));
+    BVH_HIP(hipMalloc((void **)&sorted_prim, (size_t)n * sizeof(uint32_t)));
+    BVH_HIP(hipMalloc((void **)&sorted_geom, (size_t)n * sizeof(float4)));
+    capacity = n;
+  }
+  if (!work) {
+    work = new Work();
+    BVH_HIP(hipEventCreate(&work->ev0));
+    BVH_HIP(hipEventCreate(&work->ev1));
+  }
+  const uint32_t nblk = (n + kRsTile - 1) / kRsTile;
+  if (n > work->capacity) {
+    if (work->slab) hipFree(work->slab);
+    work->slab = nullptr;
+    const size_t f4 = align256((size_t)n * sizeof(float4)), u4 = align256((size_t)n * sizeof(uint32_t));
+    const size_t hist = align256((size_t)256 * nblk * sizeof(uint32_t));
+    const size_t total = 5 * f4 + 9 * u4 + hist + 256;
+    BVH_HIP(hipMalloc((void **)&work->slab, total));
+    char *p = work->slab;
+    auto take = [&](size_t bytes) { char *q = p; p += bytes; return q; };
+    work->cr = (float4 *)take(f4);
+    work->leaf_lo = (float4 *)take(f4);
+    work->leaf_hi = (float4 *)take(f4);
+    work->box_lo = (float4 *)take(f4);
+    work->box_hi = (float4 *)take(f4);
+    work->keys[0] = (uint32_t *)take(u4);
+    work->keys[1] = (uint32_t *)take(u4);
+    work->vals[0] = (uint32_t *)take(u4);
+    work->vals[1] = (uint32_t *)take(u4);
+    work->stamp = (uint32_t *)take(u4);
+    work->left = (int *)take(u4);
+    work->right = (int *)take(u4);
+    work->parent = (int *)take(u4);
+    work->leaf_parent = (int *)take(u4);
+    work->hist = (uint32_t *)take(hist);
+    work->cbounds = (uint32_t *)take(256);
+    work->capacity = n;
+  }
+  Work &w = *work;
+
+  // ---- host prologue: (centre, radius) records and the region ray origins stay in ----------
+  std::vector<float> cr((size_t)n * 4);
+  double rsum = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const float *s = h_spheres64 + (size_t)i * 16;
+    cr[4 * (size_t)i + 0] = s[0];
+    cr[4 * (size_t)i + 1] = s[1];
+    cr[4 * (size_t)i + 2] = s[2];
+    cr[4 * (size_t)i + 3] = s[3];
+    rsum += std::fabs((double)s[3]);
+  }
+  const float r_ordinary = (float)(8.0 * rsum / n);
+  BoxParams bp;
+  float rmax_small = 0.f;
+  for (int k = 0; k < 3; ++k) bp.blo[k] = bp.bhi[k] = cam[k];
+  for (uint32_t i = 0; i < n; ++i) {
+    const float *s = &cr[4 * (size_t)i];
+    if (std::fabs(s[3]) > r_ordinary) continue;
+    rmax_small = std::max(rmax_small, std::fabs(s[3]));
+    for (int k = 0; k < 3; ++k) {
+      bp.blo[k] = std::min(bp.blo[k], s[k]);
+      bp.bhi[k] = std::max(bp.bhi[k], s[k]);
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    bp.blo[k] -= rmax_small;
+    bp.bhi[k] += rmax_small;
+  }
+
+  // ---- device build ----------------------------------------------------------------------
+  BVH_HIP(hipEventRecord(w.ev0, stream));
+  BVH_HIP(hipMemcpyAsync(w.cr, cr.data(), cr.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  BVH_HIP(hipStreamSynchronize(stream));  // cr (pageable host memory) must outlive the copy
+  BVH_HIP(hipMemsetAsync(w.cbounds, 0xff, 3 * sizeof(uint32_t), stream));      // running minima
+  BVH_HIP(hipMemsetAsync(w.cbounds + 3, 0x00, 3 * sizeof(uint32_t), stream));  // running maxima
+  const uint32_t blocks_n = (n + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(k_leaf_boxes, dim3(std::min(blocks_n, 1024u)), dim3(kThreads), 0, stream, w.cr, n,
+                     bp, w.leaf_lo, w.leaf_hi, w.cbounds);
+  hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kThreads), 0, stream, w.cr, n, w.cbounds,
+                     w.keys[0], w.vals[0]);
+  int cur = 0;
+  for (uint32_t shift = 0; shift < 32; shift += 8) {
+    hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], n, shift, w.hist,
+                       nblk);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, stream, w.hist, 256u * nblk);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], w.vals[cur],
+                       w.keys[cur ^ 1], w.vals[cur ^ 1], n, shift, w.hist, nblk);
+    cur ^= 1;
+  }
+  // sorted codes in keys[cur], sorted_prim = vals[cur]
+  BVH_HIP(hipMemcpyAsync(sorted_prim, w.vals[cur], (size_t)n * sizeof(uint32_t),
+                         hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(k_permute, dim3(blocks_n), dim3(kThreads), 0, stream, d_geom, sorted_prim,
+                     sorted_geom, n);
+  n_nodes = n - 1;
+  height = 0;
+  if (n >= 2) {
+    const uint32_t blocks_i = (n - 1 + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_hierarchy, dim3(blocks_i), dim3(kThreads), 0, stream, w.keys[cur], (int)n,
+                       w.left, w.right, w.parent, w.leaf_parent);
+    BVH_HIP(hipMemsetAsync(w.stamp, 0, (size_t)(n - 1) * sizeof(uint32_t), stream));
+    RefitView rv;
+    rv.left = w.left; rv.right = w.right; rv.parent = w.parent;
+    rv.sorted_prim = sorted_prim;
+    rv.leaf_lo = w.leaf_lo; rv.leaf_hi = w.leaf_hi;
+    rv.stamp = w.stamp; rv.box_lo = w.box_lo; rv.box_hi = w.box_hi;
+    rv.nodes = nodes;
+    rv.n_internal = (int)(n - 1);
+    uint32_t pass = 1;
+    bool done = false;
+    while (!done) {
+      for (int k = 0; k < 8; ++k, ++pass)
+        hipLaunchKernelGGL(k_refit, dim3(blocks_i), dim3(kThreads), 0, stream, rv, pass);
+      uint32_t root_stamp = 0;
+      BVH_HIP(hipMemcpyAsync(&root_stamp, w.stamp, sizeof root_stamp, hipMemcpyDeviceToHost, stream));
+      BVH_HIP(hipStreamSynchronize(stream));
+      done = root_stamp != 0u;
+      if (!done && pass > 4u * 65536u) {
+        if (err) *err = "bounds propagation did not reach the root";
+        return -2;
+      }
+    }
+    refit_passes = pass - 1;
+    float4 root_lo;
+    BVH_HIP(hipMemcpyAsync(&root_lo, w.box_lo, sizeof root_lo, hipMemcpyDeviceToHost, stream));
+    BVH_HIP(hipStreamSynchronize(stream));
+    height = (uint32_t)root_lo.w;
+  }
+  BVH_HIP(hipEventRecord(w.ev1, stream));
+  BVH_HIP(hipEventSynchronize(w.ev1));
+  BVH_HIP(hipEventElapsedTime(&last_build_ms, w.ev0, w.ev1));
+  BVH_HIP(hipGetLastError());
+  return 0;
+}
+
+int Lbvh::download(std::vector<BvhNode> *out_nodes, std::vector<uint32_t> *out_prims) const {
+  out_nodes->resize(n_nodes);
+  out_prims->resize(n_nodes + 1);
+  if (n_nodes &&
+      hipMemcpy(out_nodes->data(), nodes, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost) !=
+          hipSuccess)
+    return -2;
+  if (hipMemcpy(out_prims->data(), sorted_prim, (size_t)(n_nodes + 1) * sizeof(uint32_t),
+                hipMemcpyDeviceToHost) != hipSuccess)
+    return -2;
+  return 0;
+}
+
 }  // namespace rt

@@ -14,7 +14,7 @@
 
 namespace rt {
 
-constexpr int kBvhStack = 32;   // entries per lane; the host checks the tree depth
+constexpr int kBvhStack = kBvhStackEntries;  // entries per lane; the host checks the tree height
 constexpr int kBlockThreads = 256;
 
 __device__ __forceinline__ void sphere_candidate_tie(float4 g, int idx, f3 o, f3 d, float a,

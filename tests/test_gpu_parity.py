@@ -256,3 +256,66 @@ def test_error_paths():
             r.render(0, 1, 0)
         r.render(0, 1, 1)
         r.sync()
+
+
+# ---------------------------------------------------------------- LBVH
+def _bvh_case(oracle, n_spheres, w, h, spp, bounces, mode):
+    ubo = rt.make_ubo(w, h, spp, bounces)
+    sph = rt.grid_spheres_scene(n_spheres)
+    want = oracle.render(ubo, sph, w, h)
+    got = gpu_render(ubo, sph, w, h, mode, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+    assert got["stats"].bvh_nodes == n_spheres - 1
+    assert 0 < got["stats"].bvh_height <= 32
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+    assert np.array_equal(got["rgba8"], want["rgba8"])
+
+
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT])
+def test_lbvh_matches_brute_force_oracle(oracle, mode):
+    """The closest-hit search through the LBVH returns exactly what the shader's loop over
+    all spheres returns (lowest index among equal distances), so the whole image is
+    bit-exact against the brute-force CPU oracle."""
+    _bvh_case(oracle, 1500, 240, 135, 2, 6, mode)
+
+
+def test_lbvh_tiny_scenes(oracle):
+    w, h = 96, 64
+    ubo = rt.make_ubo(w, h, 2, 8)
+    base = rt.default_scene()
+    for n in (1, 2, 3):
+        sph = base[:n].copy()
+        want = oracle.render(ubo, sph, w, h)
+        got = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+        assert got["stats"].bvh_nodes == n - 1
+        assert np.array_equal(got["ids"], want["ids"])
+        assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+
+
+def test_lbvh_equal_distance_ties_pick_lowest_index(oracle):
+    """Coincident spheres: every hit is a tie; the shader keeps the first index."""
+    w, h = 64, 48
+    ubo = rt.make_ubo(w, h, 1, 3)
+    sph = np.repeat(rt.default_scene()[:1], 40, axis=0).copy()
+    sph[20:, 0] = 3.0  # a second stack of coincident spheres
+    want = oracle.render(ubo, sph, w, h)
+    assert set(np.unique(want["ids"])) <= {-1, 0, 20}
+    got = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+    assert np.array_equal(got["ids"], want["ids"])
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+
+
+def test_lbvh_equals_brute_force_on_gpu_at_scale():
+    """10k spheres, fast math: the LBVH and the brute-force kernels trace identical paths."""
+    w, h = 640, 360
+    ubo = rt.make_ubo(w, h, 2, 8)
+    sph = rt.grid_spheres_scene(10000)
+    a = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, rt.FLAG_FORCE_BVH)
+    b = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, rt.FLAG_FORCE_BRUTE)
+    assert a["stats"].bvh_nodes == 9999 and b["stats"].bvh_nodes == 0
+    assert np.array_equal(a["ids"], b["ids"])
+    assert a["rays"] == b["rays"]
+    assert np.array_equal(_bits(a["accum"]), _bits(b["accum"]))
+    c = gpu_render(ubo, sph, w, h, rt.MODE_WAVEFRONT, rt.FLAG_FORCE_BVH)
+    assert np.array_equal(_bits(a["accum"]), _bits(c["accum"]))

@@ -1,14 +1,16 @@
 import time, numpy as np, sys, os
 sys.path.insert(0, '.')
 import ray_tracer_amd as rt
-w,h,spp=1920,1080,64
-ubo = rt.make_ubo(w,h,spp,25); sph = rt.default_scene()
-for thr in (0, 2000, 65536, 262144, 524288, 1048576):
-    os.environ['RT_WF_DRAIN_THRESHOLD']=str(thr)
-    with rt.Renderer(w,h,mode=rt.MODE_WAVEFRONT,flags=0) as r:
+w,h,spp=1920,1080,8
+ubo = rt.make_ubo(w,h,spp,25); sph = rt.grid_spheres_scene(10000)
+for mode,name in ((rt.MODE_MEGAKERNEL,'mega'),(rt.MODE_WAVEFRONT,'wavefront')):
+  for flags,fn in ((rt.FLAG_FORCE_BVH,'bvh'),(rt.FLAG_FORCE_BRUTE,'brute')):
+    if fn=='brute' and name=='wavefront': continue
+    with rt.Renderer(w,h,mode=mode,flags=flags) as r:
         r.set_params(ubo); r.set_spheres(sph)
         r.render(0,1,1); r.sync()
+        st=r.stats(); print('build ms', st.last_build_ms, 'height', st.bvh_height, 'nodes', st.bvh_nodes)
         for k in range(2):
-            t0=time.perf_counter(); r.render(1+k,1,1); r.sync(); t1=time.perf_counter()
-            st = r.stats()
-            print('wavefront thr', thr, 'ms', st.last_render_ms, 'wall ms', (t1-t0)*1e3, 'rays', st.rays, 'launches', st.last_launches, flush=True)
+            r.render(1+k,1,1); r.sync()
+            st1 = r.stats()
+            print(name, fn, 'ms', st1.last_render_ms, 'rays/frame', st1.rays/(2+k), 'Grays/s', st1.rays/(2+k)/st1.last_render_ms/1e6, 'launches', st1.last_launches, flush=True)
