@@ -10,7 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# RT_HIP_LIB selects another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 
 MODE_MEGAKERNEL = 0
 MODE_WAVEFRONT = 1

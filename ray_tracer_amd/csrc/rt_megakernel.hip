@@ -12,6 +12,10 @@
 #include "rt_shading.h"
 #include "rt_traverse.h"
 
+#ifndef RT_MEGA_WAVES
+#define RT_MEGA_WAVES 1
+#endif
+
 namespace rt {
 
 template <bool BVH>
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
 
 // Requires n_spp >= 1 and n_bounce >= 1 (the host routes other cases to k_mega_nested).
 template <bool STRICT, bool BVH>
-__global__ __launch_bounds__(256) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+__global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   uint32_t px, py;
   pixel_of_thread(px, py);
   uint32_t nrays = 0;

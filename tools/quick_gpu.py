@@ -1,5 +1,5 @@
 import time, numpy as np, sys, os
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import ray_tracer_amd as rt
 w,h,spp=1920,1080,8
 ubo = rt.make_ubo(w,h,spp,25); sph = rt.grid_spheres_scene(10000)

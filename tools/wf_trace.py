@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import ray_tracer_amd as rt
 w,h,spp=1920,1080,64
 ubo = rt.make_ubo(w,h,spp,25); sph = rt.default_scene()
