@@ -49,10 +49,27 @@ void rt_ubo_set_camera(rt_camera *cam, rt_ubo *ubo);
 /* The three spheres of main.cpp:517-538; returns 3. */
 uint32_t rt_default_scene(rt_sphere out3[3]);
 
+/* No counterpart in the reference (it has one hard-coded scene): a deterministic synthetic
+ * scene of n spheres in the reference's record format.  Sphere 0 is the ground, centre
+ * (0,-1002,-60), radius 1000, diffuse grey; the others rest on it on a jittered square
+ * grid over x in [-50,50], z in [-110,-10], radius 0.2..0.5.  All random choices are drawn
+ * with the shader's own PCG hash (ray_tracing.comp:112-119) from `seed`, in this order
+ * per sphere: radius, x jitter, z jitter, material class, r, g, b, [class parameter].
+ * Classes: < 0.60 diffuse; < 0.85 metal (smoothness 0.5..1, specular probability 1,
+ * specular colour 0.5 + 0.5 rgb); else glossy coat (smoothness 1, specular probability
+ * 0.15..0.5).  Every 50th sphere also emits its colour with strength 4.  The reference's
+ * material has no refraction term, so there is no dielectric class.  Returns n. */
+uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out);
+
 /* Writes a binary PPM (P6) of an rgba8 image; flip_y != 0 writes the last buffer row
  * first, which is how the reference's window shows the image (negative viewport
  * height, main.cpp:934-940).  Returns 0, or -1 with errno set. */
 int rt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
+                 int flip_y);
+
+/* Same image as an 8-bit RGB PNG (stored, i.e. uncompressed, deflate blocks; no external
+ * library: the reference links stb only for reading, main.cpp:29-33). */
+int rt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
                  int flip_y);
 
 #ifdef __cplusplus

@@ -126,6 +126,7 @@ lib.rt_accum_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER
 lib.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
 lib.rt_debug_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
 lib.rt_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+lib.rt_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
 
 
 def _check(rc: int) -> None:
@@ -158,6 +159,13 @@ def write_ppm(path: str, rgba8: np.ndarray, flip_y: bool = True) -> None:
     img = np.ascontiguousarray(rgba8, dtype=np.uint8)
     if lib.rt_write_ppm(path.encode(), img.ctypes.data_as(C.c_void_p), w, h, int(flip_y)) != 0:
         raise OSError(f"rt_write_ppm({path}) failed")
+
+
+def write_png(path: str, rgba8: np.ndarray, flip_y: bool = True) -> None:
+    h, w = rgba8.shape[:2]
+    img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if lib.rt_write_png(path.encode(), img.ctypes.data_as(C.c_void_p), w, h, int(flip_y)) != 0:
+        raise OSError(f"rt_write_png({path}) failed")
 
 
 def debug_eval(op: int, a: np.ndarray, b: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:

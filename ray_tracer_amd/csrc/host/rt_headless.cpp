@@ -1,0 +1,150 @@
+// rt_headless -- the reference's main() without the window: same camera, same uniform
+// block, same frame loop (src/main.cpp:623-636 set-up, :697-703 per-frame UBO fill,
+// :1028-1031 frame counter), with every ImGui field of :712-778 as a command-line flag,
+// the compute dispatch replaced by the C ABI of librt_hip.so, and the picture written
+// to a file instead of a swapchain.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt_hip.h"
+#include "../../../include/rt_host.h"
+
+namespace {
+
+void usage() {
+  std::puts(
+      "rt_headless [options]\n"
+      "  --width W --height H        image size (default 800x608, the reference's window)\n"
+      "  --viewport reference|image  camera viewport: 800x600 as the reference leaves it, or the image size (default image)\n"
+      "  --samples N --bounces N     render settings (default 50, 25)\n"
+      "  --frames N                  progressive frames (default 1)\n"
+      "  --ground r,g,b --horizon r,g,b --zenith r,g,b --sun x,y,z\n"
+      "  --sun-focus F --sun-intensity F --defocus F --diverge F\n"
+      "  --pitch RAD --yaw RAD       camera orientation;  --rotate dx,dy  applies cameraRotate\n"
+      "  --scene default|grid:N      the reference's 3 spheres, or the synthetic N-sphere scene\n"
+      "  --mode megakernel|wavefront|nested   --strict   --linear   --brute   --bvh\n"
+      "  --device D                  HIP device ordinal\n"
+      "  --out FILE.ppm|FILE.png     shown as the reference's window shows it (bottom row first in memory)\n");
+}
+
+bool parse3(const char *s, float out[3]) { return std::sscanf(s, "%f,%f,%f", &out[0], &out[1], &out[2]) == 3; }
+
+int die(const char *what) {
+  std::fprintf(stderr, "rt_headless: %s: %s\n", what, rt_last_error());
+  return 1;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  uint32_t width = 800, height = 608, frames = 1, mode = RT_MODE_MEGAKERNEL, flags = 0;
+  int device = 0;
+  bool viewport_image = true;
+  std::string scene = "default", out_path;
+  rt_camera camera;
+  // main.cpp:624 passes window_width / window_height, an unsigned division, as the aspect
+  rt_camera_create(90.0f, (float)(800u / 608u), 0.01f, 10000.0f, &camera);
+  rt_ubo ubo;
+  rt_default_ubo(&camera, &ubo);
+  float rot[2] = {0.f, 0.f};
+  bool have_rot = false;
+
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto next = [&]() -> const char * {
+      if (i + 1 >= argc) { usage(); std::exit(2); }
+      return argv[++i];
+    };
+    if (a == "--width") width = (uint32_t)std::atoi(next());
+    else if (a == "--height") height = (uint32_t)std::atoi(next());
+    else if (a == "--viewport") viewport_image = std::string(next()) != "reference";
+    else if (a == "--samples") ubo.render_settings[0] = (float)std::atof(next());
+    else if (a == "--bounces") ubo.render_settings[1] = (float)std::atof(next());
+    else if (a == "--frames") frames = (uint32_t)std::atoi(next());
+    else if (a == "--ground") { if (!parse3(next(), ubo.ground_colour)) { usage(); return 2; } ubo.ground_colour[3] = 1.f; }
+    else if (a == "--horizon") { if (!parse3(next(), ubo.sky_colour_horizon)) { usage(); return 2; } ubo.sky_colour_horizon[3] = 1.f; }
+    else if (a == "--zenith") { if (!parse3(next(), ubo.sky_colour_zenith)) { usage(); return 2; } ubo.sky_colour_zenith[3] = 1.f; }
+    else if (a == "--sun") { if (!parse3(next(), ubo.sun_position)) { usage(); return 2; } ubo.sun_position[3] = 1.f; }
+    else if (a == "--sun-focus") ubo.sun_focus = (float)std::atof(next());
+    else if (a == "--sun-intensity") ubo.sun_intensity = (float)std::atof(next());
+    else if (a == "--defocus") ubo.defocus_strength = (float)std::atof(next());
+    else if (a == "--diverge") ubo.diverge_strength = (float)std::atof(next());
+    else if (a == "--pitch") camera.pitch = (float)std::atof(next());
+    else if (a == "--yaw") camera.yaw = (float)std::atof(next());
+    else if (a == "--rotate") { have_rot = std::sscanf(next(), "%f,%f", &rot[0], &rot[1]) == 2; }
+    else if (a == "--scene") scene = next();
+    else if (a == "--mode") {
+      const std::string m = next();
+      mode = m == "wavefront" ? RT_MODE_WAVEFRONT : m == "nested" ? RT_MODE_MEGAKERNEL_NESTED : RT_MODE_MEGAKERNEL;
+    } else if (a == "--strict") flags |= RT_FLAG_STRICT_MATH;
+    else if (a == "--linear") flags |= RT_FLAG_ACCUM_LINEAR;
+    else if (a == "--brute") flags |= RT_FLAG_FORCE_BRUTE;
+    else if (a == "--bvh") flags |= RT_FLAG_FORCE_BVH;
+    else if (a == "--device") device = std::atoi(next());
+    else if (a == "--out") out_path = next();
+    else { usage(); return a == "--help" || a == "-h" ? 0 : 2; }
+  }
+  if (viewport_image) {
+    camera.viewport_width = (float)width;
+    camera.viewport_height = (float)height;
+  }
+  if (have_rot) rt_camera_rotate(&camera, rot[0], rot[1]);  // main.cpp:692-695
+
+  std::vector<rt_sphere> spheres;
+  if (scene == "default") {
+    spheres.resize(3);
+    rt_default_scene(spheres.data());
+  } else if (scene.rfind("grid:", 0) == 0) {
+    const uint32_t n = (uint32_t)std::atoi(scene.c_str() + 5);
+    if (n == 0) { usage(); return 2; }
+    spheres.resize(n);
+    rt_grid_scene(n, 1337u, spheres.data());
+  } else { usage(); return 2; }
+
+  rt_config cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+  cfg.struct_size = sizeof cfg;
+  cfg.device = device;
+  cfg.width = width;
+  cfg.height = height;
+  cfg.mode = mode;
+  cfg.flags = flags;
+  rt_ctx *ctx = nullptr;
+  if (rt_create(&cfg, &ctx) != RT_OK) return die("rt_create");
+  if (rt_set_spheres(ctx, spheres.data(), (uint32_t)spheres.size()) != RT_OK) return die("rt_set_spheres");
+
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t frame = 0; frame < frames; ++frame) {
+    rt_ubo_set_camera(&camera, &ubo);          // main.cpp:697-701
+    ubo.frame[0] = (float)frame;               // main.cpp:1028
+    if (rt_set_params(ctx, &ubo) != RT_OK) return die("rt_set_params");   // main.cpp:703
+    if (rt_render(ctx, frame, 1, 1) != RT_OK) return die("rt_render");    // main.cpp:819-868
+  }
+  if (rt_sync(ctx) != RT_OK) return die("rt_sync");                        // main.cpp:872-874
+  const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+  rt_stats st;
+  if (rt_get_stats(ctx, &st) != RT_OK) return die("rt_get_stats");
+  std::vector<uint8_t> pixels((size_t)width * height * 4);
+  if (rt_read_rgba8(ctx, pixels.data(), pixels.size()) != RT_OK) return die("rt_read_rgba8");
+  if (!out_path.empty()) {
+    const bool png = out_path.size() > 4 && out_path.substr(out_path.size() - 4) == ".png";
+    const int rc = png ? rt_write_png(out_path.c_str(), pixels.data(), width, height, 1)
+                       : rt_write_ppm(out_path.c_str(), pixels.data(), width, height, 1);
+    if (rc != 0) { std::perror(out_path.c_str()); return 1; }
+  }
+  uint64_t sum = 0;
+  for (uint8_t v : pixels) sum += v;
+  std::printf("{\"width\": %u, \"height\": %u, \"frames\": %u, \"spheres\": %zu, \"rays\": %llu, "
+              "\"device_ms\": %.3f, \"wall_ms\": %.3f, \"mrays_per_s\": %.1f, \"bvh_nodes\": %u, "
+              "\"bvh_build_ms\": %.3f, \"image_byte_sum\": %llu}\n",
+              width, height, frames, spheres.size(), (unsigned long long)st.rays, st.total_render_ms,
+              wall_ms, st.total_render_ms > 0 ? st.rays / st.total_render_ms / 1e3 : 0.0, st.bvh_nodes,
+              st.last_build_ms, (unsigned long long)sum);
+  rt_destroy(ctx);
+  return 0;
+}

@@ -3,6 +3,7 @@
 // fp32 like glm's, trigonometry comes from the host libm like glm's std::cos/sin/tan.
 #include "../../include/rt_host.h"
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -194,6 +195,64 @@ uint32_t rt_default_scene(rt_sphere out3[3]) {
   return 3;
 }
 
+uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out) {
+  if (!out || n == 0) return 0;
+  uint32_t state = seed;
+  auto draw = [&state]() -> float {  // the shader's nextRandom / randomValue
+    state = state * 747796405u + 2891336453u;
+    uint32_t r = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+    r = (r >> 22) ^ r;
+    return (float)r * 0x1p-32f;
+  };
+  std::memset(out, 0, (size_t)n * sizeof(rt_sphere));
+  out[0].position[0] = 0.0f; out[0].position[1] = -1002.0f; out[0].position[2] = -60.0f;
+  out[0].radius = 1000.0f;
+  out[0].material.colour[0] = out[0].material.colour[1] = out[0].material.colour[2] = 0.5f;
+  out[0].material.specular_colour[0] = out[0].material.specular_colour[1] = 1.0f;
+  out[0].material.specular_colour[2] = 1.0f;
+  uint32_t side = 1;
+  while ((uint64_t)side * side < (uint64_t)(n > 1 ? n - 1 : 1)) ++side;
+  const double cell = 100.0 / side;
+  for (uint32_t i = 1; i < n; ++i) {
+    rt_sphere &s = out[i];
+    const uint32_t gx = (i - 1) % side, gz = (i - 1) / side;
+    double r = (double)draw() * 0.3 + 0.2;
+    if (cell < 1.0 && r > 0.45 * cell) r = 0.45 * cell;
+    const double x = -50.0 + (gx + 0.5 + ((double)draw() - 0.5) * 0.6) * cell;
+    const double z = -110.0 + (gz + 0.5 + ((double)draw() - 0.5) * 0.6) * cell;
+    const double dist = 1000.0 + r;
+    const double under = dist * dist - x * x - (z + 60.0) * (z + 60.0);
+    const double y = -1002.0 + std::sqrt(under > 0.0 ? under : 0.0);
+    s.position[0] = (float)x; s.position[1] = (float)y; s.position[2] = (float)z;
+    s.radius = (float)r;
+    const float kind = draw();
+    const float cr = draw(), cg = draw(), cb = draw();
+    s.material.colour[0] = cr; s.material.colour[1] = cg; s.material.colour[2] = cb;
+    if (kind < 0.60f) {
+      s.material.colour[3] = 0.0f;
+      s.material.specular_colour[0] = s.material.specular_colour[1] = 1.0f;
+      s.material.specular_colour[2] = 1.0f;
+      s.material.specular_colour[3] = 0.0f;
+    } else if (kind < 0.85f) {
+      s.material.colour[3] = 0.5f + 0.5f * draw();
+      s.material.specular_colour[0] = 0.5f + 0.5f * cr;
+      s.material.specular_colour[1] = 0.5f + 0.5f * cg;
+      s.material.specular_colour[2] = 0.5f + 0.5f * cb;
+      s.material.specular_colour[3] = 1.0f;
+    } else {
+      s.material.colour[3] = 1.0f;
+      s.material.specular_colour[0] = s.material.specular_colour[1] = 1.0f;
+      s.material.specular_colour[2] = 1.0f;
+      s.material.specular_colour[3] = 0.15f + 0.35f * draw();
+    }
+    if (i % 50 == 0) {
+      s.material.emission_colour[0] = cr; s.material.emission_colour[1] = cg;
+      s.material.emission_colour[2] = cb; s.material.emission_colour[3] = 4.0f;
+    }
+  }
+  return n;
+}
+
 int rt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
                  int flip_y) {
   if (!path || !rgba8 || !width || !height) {
@@ -221,3 +280,90 @@ int rt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_
 }
 
 }  // extern "C"
+
+namespace {
+
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    ready = true;
+  }
+  for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+  return crc;
+}
+
+void put_be32(std::vector<uint8_t> &v, uint32_t x) {
+  v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16));
+  v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+
+bool write_chunk(FILE *f, const char tag[4], const std::vector<uint8_t> &data) {
+  std::vector<uint8_t> head;
+  put_be32(head, (uint32_t)data.size());
+  uint32_t crc = crc32_update(0xffffffffu, (const uint8_t *)tag, 4);
+  crc = crc32_update(crc, data.data(), data.size()) ^ 0xffffffffu;
+  std::vector<uint8_t> tail;
+  put_be32(tail, crc);
+  return std::fwrite(head.data(), 1, 4, f) == 4 && std::fwrite(tag, 1, 4, f) == 4 &&
+         (data.empty() || std::fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+         std::fwrite(tail.data(), 1, 4, f) == 4;
+}
+
+}  // namespace
+
+extern "C" int rt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
+                            int flip_y) {
+  if (!path || !rgba8 || !width || !height) {
+    errno = EINVAL;
+    return -1;
+  }
+  // raw scanlines: filter byte 0 + RGB
+  const size_t stride = 1 + (size_t)width * 3;
+  std::vector<uint8_t> raw(stride * height);
+  for (uint32_t y = 0; y < height; ++y) {
+    const uint32_t sy = flip_y ? height - 1 - y : y;
+    const uint8_t *src = rgba8 + (size_t)sy * width * 4;
+    uint8_t *dst = raw.data() + stride * y;
+    dst[0] = 0;
+    for (uint32_t x = 0; x < width; ++x) {
+      dst[1 + 3 * (size_t)x + 0] = src[4 * (size_t)x + 0];
+      dst[1 + 3 * (size_t)x + 1] = src[4 * (size_t)x + 1];
+      dst[1 + 3 * (size_t)x + 2] = src[4 * (size_t)x + 2];
+    }
+  }
+  // zlib stream of stored blocks (at most 65535 bytes each) + Adler-32
+  std::vector<uint8_t> z;
+  z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+  z.push_back(0x78); z.push_back(0x01);
+  uint32_t a = 1, b = 0;
+  for (size_t pos = 0; pos < raw.size();) {
+    const size_t n = std::min<size_t>(65535, raw.size() - pos);
+    z.push_back(pos + n == raw.size() ? 1 : 0);
+    z.push_back((uint8_t)(n & 0xff)); z.push_back((uint8_t)(n >> 8));
+    z.push_back((uint8_t)(~n & 0xff)); z.push_back((uint8_t)((~n >> 8) & 0xff));
+    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+    for (size_t i = 0; i < n; ++i) {
+      a = (a + raw[pos + i]) % 65521u;
+      b = (b + a) % 65521u;
+    }
+    pos += n;
+  }
+  put_be32(z, (b << 16) | a);
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return -1;
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  std::vector<uint8_t> ihdr;
+  put_be32(ihdr, width);
+  put_be32(ihdr, height);
+  ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+  bool ok = std::fwrite(sig, 1, 8, f) == 8 && write_chunk(f, "IHDR", ihdr) && write_chunk(f, "IDAT", z) &&
+            write_chunk(f, "IEND", std::vector<uint8_t>());
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? 0 : -1;
+}

@@ -123,3 +123,30 @@ def test_no_gpu_fails_loudly():
         pytest.skip("a GPU is present")
     with pytest.raises(rt.RtError):
         rt.Renderer(16, 16)
+
+
+def test_write_png_round_trips(tmp_path):
+    """The PNG writer uses stored deflate blocks; decode it with zlib and compare."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(0)
+    img = (rng.random((37, 300, 4)) * 255).astype(np.uint8)   # > 65535 raw bytes: several blocks
+    p = str(tmp_path / "x.png")
+    rt.write_png(p, img, flip_y=True)
+    data = open(p, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(tag + body) == crc
+        if tag == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert ihdr == (300, 37, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(37, 1 + 300 * 3)
+    assert (raw[:, 0] == 0).all()
+    assert np.array_equal(raw[:, 1:].reshape(37, 300, 3), img[::-1, :, :3])

@@ -319,3 +319,27 @@ def test_lbvh_equals_brute_force_on_gpu_at_scale():
     assert np.array_equal(_bits(a["accum"]), _bits(b["accum"]))
     c = gpu_render(ubo, sph, w, h, rt.MODE_WAVEFRONT, rt.FLAG_FORCE_BVH)
     assert np.array_equal(_bits(a["accum"]), _bits(c["accum"]))
+
+
+def test_headless_driver_matches_the_library(tmp_path):
+    """rt_headless restates the reference's frame loop over the C ABI (per-frame
+    rt_set_params + rt_render); its picture equals the one rendered through Python."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_headless")
+    out = str(tmp_path / "h.ppm")
+    w, h = 96, 64
+    res = subprocess.run([exe, "--width", str(w), "--height", str(h), "--samples", "2", "--bounces", "5",
+                          "--frames", "3", "--strict", "--yaw", "0.3", "--out", out],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    ubo = rt.make_ubo(w, h, 2, 5, yaw=0.3)
+    got = gpu_render(ubo, rt.default_scene(), w, h, rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH, 0, 3, 1)
+    assert info["rays"] == got["rays"] and info["frames"] == 3
+    data = open(out, "rb").read()
+    head = f"P6\n{w} {h}\n255\n".encode()
+    assert data.startswith(head)
+    body = np.frombuffer(data[len(head):], dtype=np.uint8).reshape(h, w, 3)
+    assert np.array_equal(body, got["rgba8"][::-1, :, :3])
