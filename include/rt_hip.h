@@ -49,7 +49,11 @@ enum {
   /* closest-hit search: brute force over all spheres (the shader's loop) even for
    * large scenes; default is the LBVH once the scene has more than 16 spheres */
   RT_FLAG_FORCE_BRUTE = 1u << 2,
-  RT_FLAG_FORCE_BVH = 1u << 3
+  RT_FLAG_FORCE_BVH = 1u << 3,
+  /* measurement aid: megakernel + LBVH + fast math only; also counts the LBVH nodes
+   * fetched and the spheres tested (rt_stats.bvh_nodes_visited / bvh_spheres_tested).
+   * Slower; results are unchanged. */
+  RT_FLAG_COUNT_TRAVERSAL = 1u << 4
 };
 
 typedef struct rt_config {
@@ -73,6 +77,8 @@ typedef struct rt_stats {
   uint32_t bvh_nodes;       /* internal nodes of the current LBVH, 0 when brute force */
   float last_build_ms;      /* device time of the last LBVH build */
   uint32_t bvh_height;      /* longest root-to-leaf path of the LBVH, in edges */
+  uint64_t bvh_nodes_visited;   /* with RT_FLAG_COUNT_TRAVERSAL: 64-byte node fetches */
+  uint64_t bvh_spheres_tested;  /* with RT_FLAG_COUNT_TRAVERSAL: 16-byte sphere fetches */
 } rt_stats;
 
 /* Replaces createTexture(RGBA8_UNORM, W, H, STORAGE) + zero fill, main.cpp:393-448,

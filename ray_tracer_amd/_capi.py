@@ -21,6 +21,7 @@ FLAG_STRICT_MATH = 1 << 0
 FLAG_ACCUM_LINEAR = 1 << 1
 FLAG_FORCE_BRUTE = 1 << 2
 FLAG_FORCE_BVH = 1 << 3
+FLAG_COUNT_TRAVERSAL = 1 << 4
 
 
 class RtError(RuntimeError):
@@ -103,7 +104,8 @@ class _Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("last_render_ms", C.c_float),
                 ("total_render_ms", C.c_float), ("last_launches", C.c_uint32),
-                ("bvh_nodes", C.c_uint32), ("last_build_ms", C.c_float), ("bvh_height", C.c_uint32)]
+                ("bvh_nodes", C.c_uint32), ("last_build_ms", C.c_float), ("bvh_height", C.c_uint32),
+                ("bvh_nodes_visited", C.c_uint64), ("bvh_spheres_tested", C.c_uint64)]
 
 
 lib.rt_last_error.restype = C.c_char_p

@@ -129,6 +129,9 @@ rt::Scene scene_view(const rt_ctx *c) {
     S.nodes = c->bvh.nodes;
     S.sorted_prim = c->bvh.sorted_prim;
     S.sorted_geom = c->bvh.sorted_geom;
+    S.large_geom = c->bvh.large_geom;
+    S.large_prim = c->bvh.large_prim;
+    S.n_large = c->bvh.n_large;
   }
   return S;
 }
@@ -360,6 +363,9 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
   if (he == hipSuccess) {
     if (c->mode == RT_MODE_WAVEFRONT && !degenerate) {
       rc = c->wf.render(strict, c->use_bvh, c->P, S, F, O, c->stream, &launches, &err);
+    } else if ((c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->use_bvh && !strict && !degenerate) {
+      he = rt::launch_megakernel_counting(c->P, S, F, O, c->stream);
+      launches = 1;
     } else {
       const bool nested = degenerate || c->mode == RT_MODE_MEGAKERNEL_NESTED;
       he = rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream);
@@ -427,8 +433,9 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
   if (collect_timing(c, 0) != RT_OK) return RT_ERR_DEVICE;
-  unsigned long long rays = 0;
-  RT_HIP(hipMemcpy(&rays, c->d_rays, sizeof rays, hipMemcpyDeviceToHost));
+  unsigned long long counters[3] = {0, 0, 0};
+  RT_HIP(hipMemcpy(counters, c->d_rays, sizeof counters, hipMemcpyDeviceToHost));
+  const unsigned long long rays = counters[0];
   std::memset(out, 0, sizeof *out);
   out->rays = rays;
   out->frames = c->frames;
@@ -438,6 +445,8 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
   out->bvh_nodes = c->use_bvh ? c->bvh.n_nodes : 0u;
   out->last_build_ms = c->bvh.last_build_ms;
   out->bvh_height = c->use_bvh ? c->bvh.height : 0u;
+  out->bvh_nodes_visited = counters[1];
+  out->bvh_spheres_tested = counters[2];
   return RT_OK;
 }
 

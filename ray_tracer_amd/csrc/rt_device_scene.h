@@ -43,6 +43,8 @@ struct BvhNode {
 };
 
 constexpr int kBvhStackEntries = 32;  // traversal stack entries per lane (>= tree height)
+constexpr int kMaxLargeSpheres = 16;  // oversized spheres tested outside the tree
+constexpr int32_t kNullLeaf = (int32_t)0x80000000;  // leaf slot of a sphere kept out of the tree
 
 struct Scene {
   const float4 *geom;       // per sphere: centre.xyz, radius*radius   (original order)
@@ -52,6 +54,9 @@ struct Scene {
   const BvhNode *nodes;     // n_spheres-1 internal nodes, root = 0
   const uint32_t *sorted_prim;  // leaf position -> original sphere index
   const float4 *sorted_geom;    // geom[] permuted into leaf order
+  const float4 *large_geom;     // oversized spheres, tested before the tree
+  const uint32_t *large_prim;
+  uint32_t n_large;
 };
 
 struct FrameSeq {

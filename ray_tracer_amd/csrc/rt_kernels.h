@@ -11,6 +11,10 @@ namespace rt {
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
                              const FrameSeq &F, const Outputs &O, hipStream_t stream);
 
+// fast math, LBVH, nested loops, plus node/sphere tallies in O.rays[1], O.rays[2]
+hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const FrameSeq &F,
+                                      const Outputs &O, hipStream_t stream);
+
 // rt_util.hip
 hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
                           uint32_t linear_accum, hipStream_t stream);

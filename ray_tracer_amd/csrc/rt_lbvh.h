@@ -15,6 +15,9 @@ struct Lbvh {
   BvhNode *nodes = nullptr;        // n-1 internal nodes, root = 0
   uint32_t *sorted_prim = nullptr; // leaf position -> original sphere index
   float4 *sorted_geom = nullptr;   // (centre, r*r) in leaf order
+  float4 *large_geom = nullptr;    // oversized spheres kept out of the tree (centre, r*r)
+  uint32_t *large_prim = nullptr;  // their original indices, ascending
+  uint32_t n_large = 0;
   uint32_t n_nodes = 0;
   uint32_t capacity = 0;           // spheres the arrays above can hold
   uint32_t height = 0;             // longest root-to-leaf path in edges = traversal stack bound

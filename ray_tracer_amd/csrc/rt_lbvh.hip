@@ -18,6 +18,11 @@
 // the distance from the sphere to any ray origin (camera and the region the ordinary-
 // sized spheres occupy), clamped to [2^-10, 0.5].
 //
+// Oversized spheres (radius above a tenth of the extent of all centres, at most 16 of them:
+// a ground sphere, a sky dome) stay out of the tree: their box would cover every ancestor
+// on their root path and stretch the Morton grid.  Their leaves become null leaves with an
+// empty box and the traversal tests them first from a short list.
+//
 // Refit without intra-launch hand-offs.  A node may be finished in pass p only from
 // children that were finished in an EARLIER launch (their stamp is non-zero and < p), so
 // every value it reads crossed a kernel boundary; a thread that finishes a node climbs
@@ -39,6 +44,7 @@ constexpr uint32_t kRsTile = kThreads * kRsE;   // keys per block
 
 struct BoxParams {
   float blo[3], bhi[3];  // region ray origins are assumed to stay in
+  float large_radius;    // spheres above this radius are kept out of the tree
 };
 
 // order-preserving map float -> uint for atomicMin / atomicMax
@@ -83,10 +89,18 @@ __global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restric
     for (int k = 0; k < 3; ++k) {
       const float far = fmaxf(fabsf(c[k] - bp.blo[k]), fabsf(c[k] - bp.bhi[k]));
       d2 += far * far;
+    }
+    const float r = fabsf(s.w);
+    if (r > bp.large_radius) {  // null leaf: empty box, flagged in .w
+      leaf_lo[i] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 1.f);
+      leaf_hi[i] = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
+      continue;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
       mn[k] = fminf(mn[k], c[k]);
       mx[k] = fmaxf(mx[k], c[k]);
     }
-    const float r = fabsf(s.w);
     float alpha = 4.8e-7f * d2 / fmaxf(r * r, 1e-30f);
     alpha = fminf(fmaxf(alpha, 0x1p-10f), 0.5f);
     const float h = r + r * alpha + 1e-30f;
@@ -119,12 +133,18 @@ __global__ __launch_bounds__(kThreads) void k_morton(const float4 *__restrict__ 
   if (i >= n) return;
   const float4 s = cr[i];
   const float c[3] = {s.x, s.y, s.z};
+  // one scale for all axes (cubic cells): a flat scene must not spend a third of its code
+  // bits slicing its thin axis
+  float lo[3], ext = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = ord2f(cbounds[k]);
+    ext = fmaxf(ext, ord2f(cbounds[3 + k]) - lo[k]);
+  }
   uint32_t q[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float lo = ord2f(cbounds[k]), hi = ord2f(cbounds[3 + k]);
-    const float ext = hi - lo;
-    float t = ext > 0.f ? (c[k] - lo) / ext : 0.f;
+    float t = ext > 0.f ? (c[k] - lo[k]) / ext : 0.f;
     t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
     q[k] = (uint32_t)t;
   }
@@ -273,13 +293,15 @@ __device__ __forceinline__ bool child_ready(const RefitView &v, int c, uint32_t 
   const uint32_t s = v.stamp[c];
   return s != 0u && s < pass;
 }
-__device__ __forceinline__ void child_box(const RefitView &v, int c, float4 &lo, float4 &hi,
+// For a leaf of an oversized sphere, c is rewritten to kNullLeaf.
+__device__ __forceinline__ void child_box(const RefitView &v, int &c, float4 &lo, float4 &hi,
                                           float &height) {
   if (c < 0) {
     const uint32_t prim = v.sorted_prim[~c];
     lo = v.leaf_lo[prim];
     hi = v.leaf_hi[prim];
     height = 0.f;
+    if (lo.w != 0.f) c = kNullLeaf;
   } else {
     lo = v.box_lo[c];
     hi = v.box_hi[c];
@@ -307,7 +329,7 @@ __device__ __forceinline__ void finish_node(const RefitView &v, int i, int c0, i
 __global__ __launch_bounds__(kThreads) void k_refit(RefitView v, uint32_t pass) {
   int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= v.n_internal || v.stamp[i] != 0u) return;
-  const int c0 = v.left[i], c1 = v.right[i];
+  int c0 = v.left[i], c1 = v.right[i];
   if (!child_ready(v, c0, pass) || !child_ready(v, c1, pass)) return;
   float4 l0, h0, l1, h1, lo, hi;
   float ht0, ht1, height;
@@ -318,17 +340,17 @@ __global__ __launch_bounds__(kThreads) void k_refit(RefitView v, uint32_t pass) 
   for (;;) {
     const int p = v.parent[i];
     if (p < 0) break;
-    const int pc0 = v.left[p], pc1 = v.right[p];
+    int pc0 = v.left[p], pc1 = v.right[p];
     const bool i_is_left = (pc0 == i);
-    const int sib = i_is_left ? pc1 : pc0;
+    int sib = i_is_left ? pc1 : pc0;
     if (!child_ready(v, sib, pass)) break;
     float4 sl, sh;
     float sht;
     child_box(v, sib, sl, sh, sht);
     float4 nlo, nhi;
     float nh;
-    if (i_is_left) finish_node(v, p, pc0, pc1, lo, hi, height, sl, sh, sht, pass, nlo, nhi, nh);
-    else finish_node(v, p, pc0, pc1, sl, sh, sht, lo, hi, height, pass, nlo, nhi, nh);
+    if (i_is_left) finish_node(v, p, pc0, sib, lo, hi, height, sl, sh, sht, pass, nlo, nhi, nh);
+    else finish_node(v, p, sib, pc1, sl, sh, sht, lo, hi, height, pass, nlo, nhi, nh);
     lo = nlo; hi = nhi; height = nh;
     i = p;
   }
@@ -364,9 +386,14 @@ void Lbvh::release() {
   if (nodes) hipFree(nodes);
   if (sorted_prim) hipFree(sorted_prim);
   if (sorted_geom) hipFree(sorted_geom);
+  if (large_geom) hipFree(large_geom);
+  if (large_prim) hipFree(large_prim);
   nodes = nullptr;
   sorted_prim = nullptr;
   sorted_geom = nullptr;
+  large_geom = nullptr;
+  large_prim = nullptr;
+  n_large = 0;
   n_nodes = 0;
   capacity = 0;
 }
@@ -447,6 +474,40 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, cons
   }
   const float r_ordinary = (float)(8.0 * rsum / n);
   BoxParams bp;
+  {
+    // oversized spheres: radius above a tenth of the diagonal of the centres' bounds
+    float clo[3] = {cr[0], cr[1], cr[2]}, chi[3] = {cr[0], cr[1], cr[2]};
+    for (uint32_t i = 1; i < n; ++i)
+      for (int k = 0; k < 3; ++k) {
+        clo[k] = std::min(clo[k], cr[4 * (size_t)i + k]);
+        chi[k] = std::max(chi[k], cr[4 * (size_t)i + k]);
+      }
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) diag2 += ((double)chi[k] - clo[k]) * ((double)chi[k] - clo[k]);
+    bp.large_radius = n >= 3 ? (float)(0.1 * std::sqrt(diag2)) : 3.0e38f;
+    std::vector<uint32_t> big;
+    for (uint32_t i = 0; i < n; ++i)
+      if (std::fabs(cr[4 * (size_t)i + 3]) > bp.large_radius) big.push_back(i);
+    if (big.size() > (size_t)kMaxLargeSpheres || big.size() == n) {
+      bp.large_radius = 3.0e38f;  // too many to list: everything goes into the tree
+      big.clear();
+    }
+    n_large = (uint32_t)big.size();
+    std::vector<float> lg((size_t)kMaxLargeSpheres * 4, 0.f);
+    std::vector<uint32_t> li((size_t)kMaxLargeSpheres, 0u);
+    for (size_t j = 0; j < big.size(); ++j) {
+      const float *s = h_spheres64 + (size_t)big[j] * 16;
+      lg[4 * j + 0] = s[0]; lg[4 * j + 1] = s[1]; lg[4 * j + 2] = s[2];
+      lg[4 * j + 3] = s[3] * s[3];
+      li[j] = big[j];
+    }
+    if (!large_geom) {
+      BVH_HIP(hipMalloc((void **)&large_geom, kMaxLargeSpheres * sizeof(float4)));
+      BVH_HIP(hipMalloc((void **)&large_prim, kMaxLargeSpheres * sizeof(uint32_t)));
+    }
+    BVH_HIP(hipMemcpy(large_geom, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
+    BVH_HIP(hipMemcpy(large_prim, li.data(), li.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   float rmax_small = 0.f;
   for (int k = 0; k < 3; ++k) bp.blo[k] = bp.bhi[k] = cam[k];
   for (uint32_t i = 0; i < n; ++i) {

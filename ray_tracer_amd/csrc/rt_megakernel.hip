@@ -18,26 +18,14 @@
 
 namespace rt {
 
-template <bool BVH>
-__device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d) {
-  if constexpr (BVH) return closest_hit_bvh(S, o, d);
-  else return closest_hit_brute(S, o, d);
-}
-
-__device__ __forceinline__ void load_hit_sphere(const Scene &S, int idx, f3 &centre, float4 &mc,
-                                                float4 &me, float4 &ms) {
-  float4 g = S.geom[idx];
-  centre = mk3(g.x, g.y, g.z);
-  mc = S.material[3 * idx + 0];
-  me = S.material[3 * idx + 1];
-  ms = S.material[3 * idx + 2];
-}
-
-template <bool STRICT, bool BVH>
+// COUNT (only with BVH): also tallies LBVH nodes fetched and spheres tested into
+// O.rays[1] and O.rays[2].
+template <bool STRICT, bool BVH, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq F, Outputs O) {
+  __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t px, py;
   pixel_of_thread(px, py);
-  uint32_t nrays = 0;
+  uint32_t nrays = 0, cnt_nodes = 0, cnt_prims = 0;
   if (px < P.width && py < P.height) {
     const size_t pix = (size_t)py * P.width + px;
     const f3 base = pixel_direction(P, px, py);
@@ -54,7 +42,9 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
         sample_ray<STRICT>(P, base, rng, o, d);
         f3 light = mk3(0.f, 0.f, 0.f), colour = mk3(1.f, 1.f, 1.f);
         for (int b = 0; b < P.n_bounce; ++b) {
-          Hit h = closest_hit<BVH>(S, o, d);
+          Hit h;
+          if constexpr (COUNT) h = closest_hit_bvh<true>(S, o, d, stack, &cnt_nodes, &cnt_prims);
+          else h = closest_hit<BVH>(S, o, d, stack);
           ++nrays;
           if (s == 0 && b == 0) id0 = h.idx;
           if (h.idx >= 0) {
@@ -79,11 +69,19 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
   }
   uint32_t wsum = wave_sum_u32(nrays);
   if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+  if constexpr (COUNT) {
+    const uint32_t a = wave_sum_u32(cnt_nodes), b = wave_sum_u32(cnt_prims);
+    if ((threadIdx.x & 63u) == 0) {
+      atomicAdd(O.rays + 1, (unsigned long long)a);
+      atomicAdd(O.rays + 2, (unsigned long long)b);
+    }
+  }
 }
 
 // Requires n_spp >= 1 and n_bounce >= 1 (the host routes other cases to k_mega_nested).
 template <bool STRICT, bool BVH>
 __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+  __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t px, py;
   pixel_of_thread(px, py);
   uint32_t nrays = 0;
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
 
     bool active = true;
     while (active) {
-      Hit h = closest_hit<BVH>(S, o, d);
+      Hit h = closest_hit<BVH>(S, o, d, stack);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
@@ -160,6 +158,13 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     hipLaunchKernelGGL((k_mega_nested<STRICT, BVH>), grid, block, 0, stream, P, S, F, O);
   else
     hipLaunchKernelGGL((k_mega_regen<STRICT, BVH>), grid, block, 0, stream, P, S, F, O);
+  return hipGetLastError();
+}
+
+hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const FrameSeq &F,
+                                      const Outputs &O, hipStream_t stream) {
+  dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
+  hipLaunchKernelGGL((k_mega_nested<false, true, true>), grid, dim3(256), 0, stream, P, S, F, O);
   return hipGetLastError();
 }
 

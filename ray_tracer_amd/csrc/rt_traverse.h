@@ -47,8 +47,14 @@ __device__ __forceinline__ float slab_entry(const float lo[3], const float hi[3]
   return tn <= tf ? tn : __builtin_inff();
 }
 
-__device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d) {
-  __shared__ int stack[kBvhStack][kBlockThreads];
+// COUNT adds two per-lane tallies (nodes fetched, spheres tested) for the roofline's
+// bytes-per-segment figure; the search itself is identical.
+// `stack` points at kBvhStack * kBlockThreads ints of LDS owned by the calling kernel
+// (entry-major); it is scratch, so a kernel may reuse that memory between searches.
+template <bool COUNT = false>
+__device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *stack,
+                                               uint32_t *n_nodes = nullptr,
+                                               uint32_t *n_prims = nullptr) {
   const int tid = threadIdx.x;
   Hit best;
   best.dst = 3.402823466e+38f;
@@ -57,41 +63,75 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d) {
   const float a = dot(d, d);
   const f3 inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
                        __builtin_amdgcn_rcpf(d.z));
+  for (uint32_t i = 0; i < S.n_large; ++i) {
+    sphere_candidate_tie(S.large_geom[i], (int)S.large_prim[i], o, d, a, best_n, best);
+    if constexpr (COUNT) ++*n_prims;
+  }
   if (S.n_spheres == 1u) {
-    sphere_candidate_tie(S.sorted_geom[0], (int)S.sorted_prim[0], o, d, a, best_n, best);
+    if (S.n_large == 0u) {
+      sphere_candidate_tie(S.sorted_geom[0], (int)S.sorted_prim[0], o, d, a, best_n, best);
+      if constexpr (COUNT) ++*n_prims;
+    }
   } else {
     int sp = 0;
     int node = 0;
     while (true) {
       const BvhNode nd = S.nodes[node];
+      if constexpr (COUNT) ++*n_nodes;
       // the distance limit carries slack: box arithmetic rounds, the sphere test decides
       const float limit = __builtin_fmaf(best.dst, 1.0e-4f, best.dst);
       float t0 = slab_entry(nd.lo0, nd.hi0, o, inv_d, limit);
       float t1 = slab_entry(nd.lo1, nd.hi1, o, inv_d, limit);
       int c0 = nd.child0, c1 = nd.child1;
       if (t0 < __builtin_inff() && c0 < 0) {
-        sphere_candidate_tie(S.sorted_geom[~c0], (int)S.sorted_prim[~c0], o, d, a, best_n, best);
+        if (c0 != kNullLeaf) {
+          sphere_candidate_tie(S.sorted_geom[~c0], (int)S.sorted_prim[~c0], o, d, a, best_n, best);
+          if constexpr (COUNT) ++*n_prims;
+        }
         t0 = __builtin_inff();
       }
       if (t1 < __builtin_inff() && c1 < 0) {
-        sphere_candidate_tie(S.sorted_geom[~c1], (int)S.sorted_prim[~c1], o, d, a, best_n, best);
+        if (c1 != kNullLeaf) {
+          sphere_candidate_tie(S.sorted_geom[~c1], (int)S.sorted_prim[~c1], o, d, a, best_n, best);
+          if constexpr (COUNT) ++*n_prims;
+        }
         t1 = __builtin_inff();
       }
       const bool go0 = t0 < __builtin_inff(), go1 = t1 < __builtin_inff();
       if (go0 && go1) {
         const bool first0 = t0 <= t1;
-        stack[sp++][tid] = first0 ? c1 : c0;
+        stack[(sp++) * kBlockThreads + tid] = first0 ? c1 : c0;
         node = first0 ? c0 : c1;
       } else if (go0 || go1) {
         node = go0 ? c0 : c1;
       } else {
         if (sp == 0) break;
-        node = stack[--sp][tid];
+        node = stack[(--sp) * kBlockThreads + tid];
       }
     }
   }
   if (best.idx == 0x7fffffff) best.idx = -1;
   return best;
+}
+
+// closest hit through whichever structure the kernel was built for
+template <bool BVH>
+__device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stack) {
+  if constexpr (BVH) return closest_hit_bvh(S, o, d, stack);
+  else return closest_hit_brute(S, o, d);
+}
+
+// LDS words a kernel must provide for the traversal stack (1 keeps the array legal)
+template <bool BVH>
+constexpr int bvh_stack_words() { return BVH ? kBvhStack * kBlockThreads : 1; }
+
+__device__ __forceinline__ void load_hit_sphere(const Scene &S, int idx, f3 &centre, float4 &mc,
+                                                float4 &me, float4 &ms) {
+  float4 g = S.geom[idx];
+  centre = mk3(g.x, g.y, g.z);
+  mc = S.material[3 * idx + 0];
+  me = S.material[3 * idx + 1];
+  ms = S.material[3 * idx + 2];
 }
 
 }  // namespace rt

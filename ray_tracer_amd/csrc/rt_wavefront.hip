@@ -101,6 +101,7 @@ template <bool BVH>
 __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t slot, uint32_t n_pixels,
                                                    int32_t *ids) {
   __shared__ uint32_t lds[kWfE * 4 + 1];
+  __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t *cnt = V.counts + 4u * (slot & 3u);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     uint32_t *z = V.counts + 4u * ((slot + 1u) & 3u);
@@ -116,9 +117,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
     is_hit[k] = is_miss[k] = false;
     if (pix[k] < n_pixels && V.alive[pix[k]]) {
       const float4 p0 = V.P0[pix[k]], p1 = V.P1[pix[k]];
-      Hit h;
-      if constexpr (BVH) h = closest_hit_bvh(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z));
-      else h = closest_hit_brute(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z));
+      const Hit h = closest_hit<BVH>(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), stack);
       V.H[pix[k]] = make_float2(h.dst, __int_as_float(h.idx));
       if (__float_as_uint(p1.w) == 0u) ids[pix[k]] = h.idx;  // sample 0, bounce 0
       is_hit[k] = h.idx >= 0;
@@ -231,6 +230,7 @@ __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels)
 template <bool STRICT, bool BVH>
 __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, uint32_t frame,
                                                   Outputs O) {
+  __shared__ int stack[bvh_stack_words<BVH>()];
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
   uint32_t nrays = 0;
@@ -247,9 +247,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
     f3 total = mk3(t.x, t.y, t.z);
     int id0 = -2;
     while (true) {
-      Hit h;
-      if constexpr (BVH) h = closest_hit_bvh(S, o, d);
-      else h = closest_hit_brute(S, o, d);
+      const Hit h = closest_hit<BVH>(S, o, d, stack);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
