@@ -405,9 +405,12 @@ static inline hit_t closest_hit(const frame_ctx *fc, v3 o, v3 d) {
 }
 
 static inline float clamp01(float t) { return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t); }
-/* GLSL smoothstep: t = clamp((x-e0)/(e1-e0),0,1); t*t*(3-2t) */
+/* GLSL smoothstep: t = clamp((x-e0)/(e1-e0),0,1); t*t*(3-2t).  The quotient is taken as
+ * (x-e0) * k with k = 1/(e1-e0) rounded to fp32 once -- one of the evaluations GLSL's
+ * 2.5-ulp bound on '/' allows, and the one this oracle pins. */
 static inline float smoothstepf(float e0, float e1, float x) {
-  float t = clamp01((x - e0) / (e1 - e0));
+  const float k = 1.0f / (e1 - e0);
+  float t = clamp01((x - e0) * k);
   return (t * t) * (3.0f - 2.0f * t);
 }
 

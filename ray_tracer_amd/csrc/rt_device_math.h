@@ -51,8 +51,14 @@ __device__ __forceinline__ f3 mix3(f3 x, f3 y, float a) {
 
 // IEEE-754 correctly rounded square root and quotient (hipcc's default for
 // sqrtf and '/' on fp32; the bit-for-bit property is checked by the GPU tests).
+#ifdef RT_MEASURE_APPROX_GEOMETRY
+// measurement-only build: what the IEEE requirement costs (results are NOT exact)
+__device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float ieee_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
 __device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
+#endif
 __device__ __forceinline__ f3 ieee_normalize(f3 v) {
   float inv = ieee_div(1.0f, ieee_sqrt(dot(v, v)));
   return v * inv;

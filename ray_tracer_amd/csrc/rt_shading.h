@@ -116,16 +116,20 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d) {
 
 // ---- environment (ray_tracing.comp:239-250) ----------------------------------------
 __device__ __forceinline__ float clamp01(float t) { return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t); }
-__device__ __forceinline__ float smoothstep_div(float e0, float e1, float x) {
-  float t = clamp01(ieee_div(x - e0, e1 - e0));
+// GLSL smoothstep(e0, e1, x): t = clamp((x - e0) / (e1 - e0), 0, 1); t*t*(3 - 2t).  Both
+// call sites have constant edges, and the quotient is taken as (x - e0) * k with
+// k = 1 / (e1 - e0) rounded to fp32 once (2.5 for 0.4, 100 for 0.01): within GLSL's
+// 2.5-ulp bound for '/', and the same on CPU and GPU.
+__device__ __forceinline__ float smoothstep_rcp(float e0, float k, float x) {
+  float t = clamp01((x - e0) * k);
   return (t * t) * (3.0f - 2.0f * t);
 }
 
 template <bool STRICT>
 __device__ __forceinline__ f3 environment(const Params &P, f3 d) {
   using M = Math<STRICT>;
-  float sky_t = M::pow(smoothstep_div(0.0f, 0.4f, d.y), 0.35f);
-  float g2s = smoothstep_div(-0.01f, 0.0f, d.y);
+  float sky_t = M::pow(smoothstep_rcp(0.0f, 2.5f, d.y), 0.35f);          // edges 0, 0.4
+  float g2s = smoothstep_rcp(-0.01f, 100.0f, d.y);                       // edges -0.01, 0
   f3 sky = mix3(mk3(P.horizon[0], P.horizon[1], P.horizon[2]),
                 mk3(P.zenith[0], P.zenith[1], P.zenith[2]), sky_t);
   float sd = dot(d, mk3(P.sun[0], P.sun[1], P.sun[2]));
