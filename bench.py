@@ -65,6 +65,19 @@ def cpu_baseline(ubo, spheres, threads: int):
     }
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the benchmarked kernel from the committed rocprofv3 --pmc
+    passes (profiles/: FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE).
+    bench.py cannot collect hardware counters itself; None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d["hbm_bytes_per_launch"]), d.get("source", path)
+    except Exception:
+        return None, None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +148,21 @@ def main() -> None:
 
     rays = float(st1.rays - st0.rays)
     kernel_ms = float(st1.total_render_ms - st0.total_render_ms)
+
+    # configs[1] asks for "megakernel vs wavefront": time a few frames of the other
+    # organisation outside the timed region (rank 0 of a single-GPU run only)
+    other_ms = None
+    if world == 1 and args.mode == "megakernel":
+        with rt.Renderer(WIDTH, HEIGHT, mode=rt.MODE_WAVEFRONT, device=local_rank) as wf:
+            wf.set_params(ubo)
+            wf.set_spheres(spheres)
+            wf.render(0, 1, 1)
+            wf.stats()
+            t = []
+            for f in range(1, 4):
+                wf.render(f, 1, 1)
+                t.append(wf.stats().last_render_ms)
+            other_ms = sorted(t)[1]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,6 +178,7 @@ def main() -> None:
         launch_ms = kernel_ms / max(args.steps, 1)          # rank 0's render launches, HIP events
         flops = algorithmic_flops(rays, samples, n_spheres) / max(args.steps, 1)
         achieved = flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_bytes() if args.mode == "megakernel" else (None, None)
         out = {
             "metric": "Mrays/sec (all bounces)",
             "value": total_rays / elapsed / 1e6,
@@ -172,6 +201,7 @@ def main() -> None:
                 "parallelism": f"frame-split x{world}" + (" + RCCL reduce" if world > 1 else ""),
                 "ms_per_frame_1080p_64spp": launch_ms,
                 "rays_per_frame": rays / max(args.steps, 1),
+                "wavefront_ms_per_frame_1080p_64spp": other_ms,
             },
             "roofline": {
                 "bound": "valu",
@@ -181,7 +211,8 @@ def main() -> None:
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launch_ms": launch_ms,
                 "algorithmic_flops_per_launch": flops,
                 "note": "branchy FP32 vector work, no dense contraction: priced against the FP32 "
