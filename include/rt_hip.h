@@ -98,6 +98,15 @@ int rt_set_params(rt_ctx *ctx, const void *ubo272);
  * of 64 bytes (rt_sphere).  Rebuilds the acceleration structure when one is used. */
 int rt_set_spheres(rt_ctx *ctx, const void *spheres64, uint32_t count);
 
+/* No counterpart in the reference, which traces spheres only (assimp is linked but never
+ * called, CMakeLists.txt:12): an indexed triangle mesh with ONE material, traced together
+ * with the spheres.  vertices = n_vertices * xyz (12-byte stride), indices = 3 per
+ * triangle.  Primitive ids of triangles follow the spheres: n_spheres + triangle index.
+ * Both faces are hit; the shading normal is the geometric normal turned against the ray.
+ * n_triangles = 0 removes the mesh.  Rebuilds the acceleration structure. */
+int rt_set_mesh(rt_ctx *ctx, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
+                uint32_t n_triangles, const rt_material *material);
+
 /* Replaces bind pipeline + descriptor sets + vkCmdDispatch(W/16,H/16,1) + submit,
  * main.cpp:819-868, for n_frames dispatches with ubo.frame.x = first_frame,
  * first_frame + frame_stride, ...  (main.cpp:1028 increments it by one per

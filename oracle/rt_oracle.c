@@ -364,6 +364,7 @@ typedef struct {
   /* scene */
   const float *spheres; /* 16 floats per sphere */
   uint32_t n_spheres;
+  const rto_mesh *mesh; /* optional triangle mesh (extension, see rt_oracle.h) */
   uint32_t width, height;
   const math_ops *mo;
 } frame_ctx;
@@ -391,8 +392,49 @@ static inline hit_t ray_sphere(v3 o, v3 d, v3 centre, float radius) {
   return h;
 }
 
-/* calculateRayCollision, ray_tracing.comp:172-190 */
-static inline hit_t closest_hit(const frame_ctx *fc, v3 o, v3 d) {
+/* a x b with the second product of each component fused into the difference */
+static inline v3 v_cross(v3 a, v3 b) {
+  return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+/* Ray-triangle test (extension: the reference has spheres only).  Moeller-Trumbore with the
+ * barycentric tests done on the un-divided numerators, so only an accepted hit divides:
+ *   e1 = v1-v0, e2 = v2-v0, p = d x e2, det = e1.p          (det == 0: parallel, miss)
+ *   tv = o-v0, un = tv.p, q = tv x e1, vn = d.q, tn = e2.q
+ *   with s = sign(det): s*un >= 0, s*vn >= 0, s*(un+vn) <= s*det, s*tn >= 0   else miss
+ *   dst = tn / det;  point = o + d*dst;  normal = normalize(e1 x e2), turned against d
+ * Both faces are hit. */
+static inline hit_t ray_triangle(v3 o, v3 d, v3 v0, v3 v1, v3 v2) {
+  hit_t h;
+  h.hit = 0; h.dst = 0.0f; h.point = V3(0, 0, 0); h.normal = V3(0, 0, 0); h.index = -1;
+  v3 e1 = v_sub(v1, v0), e2 = v_sub(v2, v0);
+  v3 p = v_cross(d, e2);
+  float det = v_dot(e1, p);
+  if (!(det != 0.0f)) return h;                 /* zero or NaN */
+  float s = det > 0.0f ? 1.0f : -1.0f;
+  v3 tv = v_sub(o, v0);
+  float un = v_dot(tv, p);
+  if (!(un * s >= 0.0f)) return h;
+  v3 q = v_cross(tv, e1);
+  float vn = v_dot(d, q);
+  if (!(vn * s >= 0.0f) || !((un + vn) * s <= det * s)) return h;
+  float tn = v_dot(e2, q);
+  if (!(tn * s >= 0.0f)) return h;
+  h.hit = 1;
+  h.dst = tn / det;
+  h.point = v_fma(d, h.dst, o);
+  v3 n = v_normalize(v_cross(e1, e2));
+  if (v_dot(n, d) > 0.0f) n = V3(-n.x, -n.y, -n.z);
+  h.normal = n;
+  return h;
+}
+
+/* calculateRayCollision, ray_tracing.comp:172-190, extended over the mesh: primitive ids
+ * are sphere indices followed by n_spheres + triangle index; strict "<" keeps the lowest
+ * id among equal distances.  skip is the triangle the ray starts on (-1: none): a planar
+ * primitive cannot be hit again by a ray leaving it, and without an epsilon the test
+ * above would report it at dst = 0. */
+static inline hit_t closest_hit(const frame_ctx *fc, v3 o, v3 d, int skip) {
   hit_t best;
   best.hit = 0; best.dst = 3.402823466e+38f;
   best.point = V3(0, 0, 0); best.normal = V3(0, 0, 0); best.index = -1;
@@ -400,6 +442,18 @@ static inline hit_t closest_hit(const frame_ctx *fc, v3 o, v3 d) {
     const float *s = fc->spheres + 16u * i;
     hit_t h = ray_sphere(o, d, V3(s[0], s[1], s[2]), s[3]);
     if (h.hit && h.dst < best.dst) { best = h; best.index = (int)i; }
+  }
+  if (fc->mesh) {
+    const rto_mesh *m = fc->mesh;
+    for (uint32_t t = 0; t < m->n_triangles; ++t) {
+      const int id = (int)(fc->n_spheres + t);
+      if (id == skip) continue;
+      const float *a = m->vertices + 3u * m->indices[3u * t + 0];
+      const float *b = m->vertices + 3u * m->indices[3u * t + 1];
+      const float *c = m->vertices + 3u * m->indices[3u * t + 2];
+      hit_t h = ray_triangle(o, d, V3(a[0], a[1], a[2]), V3(b[0], b[1], b[2]), V3(c[0], c[1], c[2]));
+      if (h.hit && h.dst < best.dst) { best = h; best.index = id; }
+    }
   }
   return best;
 }
@@ -451,12 +505,16 @@ static inline void point_in_circle(const frame_ctx *fc, uint32_t *rng, float out
 static inline v3 trace_path(const frame_ctx *fc, v3 o, v3 d, uint32_t *rng, int *first_id,
                             uint64_t *rays) {
   v3 light = V3(0, 0, 0), colour = V3(1, 1, 1);
+  int skip = -1;
   for (int i = 0; (float)i < fc->max_bounce; ++i) {
-    hit_t h = closest_hit(fc, o, d);
+    hit_t h = closest_hit(fc, o, d, skip);
     ++*rays;
     if (i == 0 && first_id) *first_id = h.hit ? h.index : -1;
     if (h.hit) {
-      const float *m = fc->spheres + 16u * (uint32_t)h.index + 4;  /* colour, emission, specular */
+      /* colour, emission, specular: the sphere's own, or the mesh's one material */
+      const float *m = (uint32_t)h.index < fc->n_spheres ? fc->spheres + 16u * (uint32_t)h.index + 4
+                                                         : fc->mesh->material;
+      skip = (uint32_t)h.index < fc->n_spheres ? -1 : h.index;
       o = h.point;
       v3 diffuse = v_normalize(v_add(h.normal, random_direction(fc, rng)));
       float dn2 = 2.0f * v_dot(h.normal, d);                      /* reflect(I,N) = I - 2 dot(N,I) N */
@@ -556,7 +614,20 @@ int rto_render(const void *ubo272, const void *spheres64, uint32_t n_spheres, ui
                uint32_t height, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
                int math_mode, int accum_mode, float *accum, uint8_t *rgba8, int32_t *ids,
                uint64_t *rays, int threads) {
+  return rto_render_mesh(ubo272, spheres64, n_spheres, NULL, width, height, first_frame, n_frames,
+                         frame_stride, math_mode, accum_mode, accum, rgba8, ids, rays, threads);
+}
+
+int rto_render_mesh(const void *ubo272, const void *spheres64, uint32_t n_spheres,
+                    const rto_mesh *mesh, uint32_t width, uint32_t height, uint32_t first_frame,
+                    uint32_t n_frames, uint32_t frame_stride, int math_mode, int accum_mode,
+                    float *accum, uint8_t *rgba8, int32_t *ids, uint64_t *rays, int threads) {
   if (!ubo272 || (!spheres64 && n_spheres) || !width || !height) return -1;
+  if (mesh && mesh->n_triangles == 0) mesh = NULL;
+  if (mesh && (!mesh->vertices || !mesh->indices || !mesh->material)) return -1;
+  if (mesh)
+    for (uint32_t k = 0; k < 3u * mesh->n_triangles; ++k)
+      if (mesh->indices[k] >= mesh->n_vertices) return -1;
   if (threads <= 0) threads = 1;
   if (threads > 256) threads = 256;
   float u[68];
@@ -573,6 +644,7 @@ int rto_render(const void *ubo272, const void *spheres64, uint32_t n_spheres, ui
   fc.sun_pos = V3(u[60], u[61], u[62]);
   fc.sun_focus = u[64]; fc.sun_intensity = u[65]; fc.defocus = u[66]; fc.diverge = u[67];
   fc.spheres = (const float *)spheres64; fc.n_spheres = n_spheres;
+  fc.mesh = mesh;
   fc.width = width; fc.height = height;
   fc.mo = math_mode == RTO_MATH_LIBM ? &k_libm : &k_portable;
 

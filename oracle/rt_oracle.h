@@ -100,6 +100,23 @@ int rto_render(const void *ubo272, const void *spheres64, uint32_t n_spheres,
                int accum_mode, float *accum, uint8_t *rgba8, int32_t *ids,
                uint64_t *rays, int threads);
 
+/* Triangle mesh (EXTENSION: the reference traces spheres only; BASELINE.json asks for
+ * triangles).  One material for the whole mesh.  Primitive ids of triangles follow the
+ * spheres: n_spheres + triangle index.  Intersection rule: see ray_triangle() in
+ * rt_oracle.c. */
+typedef struct rto_mesh {
+  const float *vertices;      /* xyz, 12-byte stride */
+  uint32_t n_vertices;
+  const uint32_t *indices;    /* three per triangle */
+  uint32_t n_triangles;
+  const float *material;      /* 12 floats: colour, emissionColour, specularColour */
+} rto_mesh;
+
+int rto_render_mesh(const void *ubo272, const void *spheres64, uint32_t n_spheres,
+                    const rto_mesh *mesh, uint32_t width, uint32_t height, uint32_t first_frame,
+                    uint32_t n_frames, uint32_t frame_stride, int math_mode, int accum_mode,
+                    float *accum, uint8_t *rgba8, int32_t *ids, uint64_t *rays, int threads);
+
 /* accum (rgb sum, a = frame count) -> rgba8 with the image-store conversion */
 void rto_resolve_rgba8(const float *accum, uint32_t n_pixels, int accum_mode,
                        uint8_t *rgba8);

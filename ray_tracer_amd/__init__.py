@@ -28,11 +28,11 @@ from ._capi import (  # noqa: F401
     write_png,
     write_ppm,
 )
-from .scenes import grid_spheres_scene, make_ubo  # noqa: F401
+from .scenes import grid_spheres_scene, make_ubo, matte, terrain_mesh  # noqa: F401
 
 __all__ = [
     "LIB_PATH", "MODE_MEGAKERNEL", "MODE_MEGAKERNEL_NESTED", "MODE_WAVEFRONT",
     "FLAG_ACCUM_LINEAR", "FLAG_COUNT_TRAVERSAL", "FLAG_FORCE_BRUTE", "FLAG_FORCE_BVH", "FLAG_STRICT_MATH",
     "Camera", "Renderer", "RtError", "Stats", "debug_eval", "default_scene", "default_ubo",
-    "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "make_ubo",
+    "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "make_ubo", "matte", "terrain_mesh",
 ]

@@ -117,6 +117,7 @@ lib.rt_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
 lib.rt_destroy.argtypes = [C.c_void_p]
 lib.rt_set_params.argtypes = [C.c_void_p, C.c_void_p]
 lib.rt_set_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+lib.rt_set_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
 lib.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.rt_sync.argtypes = [C.c_void_p]
 lib.rt_clear.argtypes = [C.c_void_p]
@@ -219,6 +220,15 @@ class Renderer:
     def set_spheres(self, spheres: np.ndarray) -> None:
         spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 16)
         _check(lib.rt_set_spheres(self._ctx, spheres.ctypes.data_as(C.c_void_p), spheres.shape[0]))
+
+    def set_mesh(self, vertices: np.ndarray, indices: np.ndarray, material: np.ndarray) -> None:
+        """vertices (n,3) float32, indices (m,3) uint32, material (12,) float32 = colour,
+        emissionColour, specularColour."""
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        m = np.ascontiguousarray(material, dtype=np.float32).reshape(12)
+        _check(lib.rt_set_mesh(self._ctx, v.ctypes.data_as(C.c_void_p), v.shape[0],
+                               i.ctypes.data_as(C.c_void_p), i.shape[0], m.ctypes.data_as(C.c_void_p)))
 
     def render(self, first_frame: int = 0, n_frames: int = 1, stride: int = 1) -> None:
         _check(lib.rt_render(self._ctx, first_frame, n_frames, stride))

@@ -63,6 +63,11 @@ struct rt_ctx {
   bool have_scene = false;
   std::vector<float> h_spheres;  // the 64-byte records as uploaded (for rebuilds)
 
+  float4 *d_tri = nullptr;       // v0, v1, v2 per mesh triangle
+  uint32_t n_tris = 0;
+  std::vector<float> h_tri9;     // the same, 9 floats per triangle (for rebuilds)
+  float mesh_material[12] = {0};
+
   rt::Lbvh bvh;                  // device LBVH + build workspace
   bool use_bvh = false;
   float bvh_cam[3] = {0.f, 0.f, 0.f};  // camera position the leaf boxes were sized for
@@ -125,6 +130,8 @@ rt::Scene scene_view(const rt_ctx *c) {
   S.geom = c->d_geom;
   S.material = c->d_material;
   S.n_spheres = c->n_spheres;
+  S.tri = c->d_tri;
+  S.n_tris = c->n_tris;
   if (c->use_bvh) {
     S.nodes = c->bvh.nodes;
     S.sorted_prim = c->bvh.sorted_prim;
@@ -134,6 +141,27 @@ rt::Scene scene_view(const rt_ctx *c) {
     S.n_large = c->bvh.n_large;
   }
   return S;
+}
+
+// (Re)builds the LBVH over spheres + mesh when the scene is large enough or forced.
+int rebuild_accel(rt_ctx *c) {
+  const uint32_t n_prims = c->n_spheres + c->n_tris;
+  c->use_bvh = false;
+  const bool want = (c->flags & RT_FLAG_FORCE_BVH) != 0 ||
+                    (!(c->flags & RT_FLAG_FORCE_BRUTE) && n_prims > 16u);
+  if (!want || n_prims == 0) return RT_OK;
+  std::string err;
+  const float cam[3] = {c->have_params ? c->P.cam_x : 0.f, c->have_params ? c->P.cam_y : 0.f,
+                        c->have_params ? c->P.cam_z : 0.f};
+  int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), c->n_spheres, c->d_tri, c->h_tri9.data(),
+                        c->n_tris, cam, c->stream, &err);
+  if (rc != RT_OK) return fail(rc, "LBVH build: %s", err.c_str());
+  if (c->bvh.height > (uint32_t)rt::kBvhStackEntries)
+    return fail(RT_ERR_INVALID, "LBVH height %u exceeds the traversal stack (%d)", c->bvh.height,
+                rt::kBvhStackEntries);
+  std::memcpy(c->bvh_cam, cam, sizeof cam);
+  c->use_bvh = true;
+  return RT_OK;
 }
 
 }  // namespace
@@ -211,6 +239,7 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_rays) hipFree(c->d_rays);
   if (c->d_geom) hipFree(c->d_geom);
   if (c->d_material) hipFree(c->d_material);
+  if (c->d_tri) hipFree(c->d_tri);
   c->bvh.release();
   c->wf.release();
   for (auto &p : c->ev_pending) c->ev_free.push_back(p);
@@ -275,10 +304,9 @@ int rt_set_params(rt_ctx *c, const void *ubo272) {
     // leaf boxes are sized from the distance to the camera: rebuild for the new position
     RT_HIP(hipSetDevice(c->device));
     RT_HIP(hipStreamSynchronize(c->stream));
-    std::string err;
+    int rc = rebuild_accel(c);
+    if (rc != RT_OK) return rc;
     const float cam[3] = {P.cam_x, P.cam_y, P.cam_z};
-    int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), c->n_spheres, cam, c->stream, &err);
-    if (rc != RT_OK) return fail(rc, "rt_set_params: LBVH rebuild: %s", err.c_str());
     std::memcpy(c->bvh_cam, cam, sizeof cam);
   }
   return RT_OK;
@@ -298,7 +326,9 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
   c->use_bvh = false;
   const size_t alloc_n = count ? count : 1;
   RT_HIP(hipMalloc(&c->d_geom, alloc_n * sizeof(float4)));
-  RT_HIP(hipMalloc(&c->d_material, alloc_n * 3 * sizeof(float4)));
+  RT_HIP(hipMalloc(&c->d_material, ((size_t)count + 1) * 3 * sizeof(float4)));  // + the mesh's
+  RT_HIP(hipMemcpy(c->d_material + 3 * (size_t)count, c->mesh_material, sizeof c->mesh_material,
+                   hipMemcpyHostToDevice));
   c->h_spheres.assign((const float *)spheres64, (const float *)spheres64 + (size_t)count * 16);
   if (count) {
     // repack the 64-byte records: geometry (centre, r*r) apart from the material,
@@ -317,20 +347,51 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
     RT_HIP(hipMemcpy(c->d_material, mat.data(), mat.size() * sizeof(float),
                      hipMemcpyHostToDevice));
   }
-  bool want_bvh = (c->flags & RT_FLAG_FORCE_BVH) != 0 ||
-                  (!(c->flags & RT_FLAG_FORCE_BRUTE) && count > 16u);
-  if (want_bvh && count >= 1) {
-    std::string err;
-    const float cam[3] = {c->have_params ? c->P.cam_x : 0.f, c->have_params ? c->P.cam_y : 0.f,
-                          c->have_params ? c->P.cam_z : 0.f};
-    int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), count, cam, c->stream, &err);
-    if (rc != RT_OK) return fail(rc, "rt_set_spheres: LBVH build: %s", err.c_str());
-    if (c->bvh.height > (uint32_t)rt::kBvhStackEntries)
-      return fail(RT_ERR_INVALID, "rt_set_spheres: LBVH height %u exceeds the traversal stack (%d)",
-                  c->bvh.height, rt::kBvhStackEntries);
-    std::memcpy(c->bvh_cam, cam, sizeof cam);
-    c->use_bvh = true;
+  int rc = rebuild_accel(c);
+  if (rc != RT_OK) return rc;
+  c->have_scene = true;
+  return RT_OK;
+}
+
+int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
+                uint32_t n_triangles, const rt_material *material) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_set_mesh: null context");
+  if (n_triangles && (!vertices || !indices || !material))
+    return fail(RT_ERR_INVALID, "rt_set_mesh: null data");
+  if (n_triangles > (1u << 26)) return fail(RT_ERR_INVALID, "rt_set_mesh: %u triangles", n_triangles);
+  for (size_t k = 0; k < (size_t)n_triangles * 3; ++k)
+    if (indices[k] >= n_vertices)
+      return fail(RT_ERR_INVALID, "rt_set_mesh: index %u at position %zu, %u vertices", indices[k], k,
+                  n_vertices);
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_tri) RT_HIP(hipFree(c->d_tri));
+  c->d_tri = nullptr;
+  c->n_tris = n_triangles;
+  c->h_tri9.resize((size_t)n_triangles * 9);
+  if (material) std::memcpy(c->mesh_material, material, sizeof c->mesh_material);
+  if (n_triangles) {
+    std::vector<float> t4((size_t)n_triangles * 12, 0.f);
+    for (size_t t = 0; t < n_triangles; ++t)
+      for (int v = 0; v < 3; ++v) {
+        const float *src = vertices + 3 * (size_t)indices[3 * t + v];
+        for (int k = 0; k < 3; ++k) {
+          c->h_tri9[9 * t + 3 * v + k] = src[k];
+          t4[12 * t + 4 * v + k] = src[k];
+        }
+      }
+    RT_HIP(hipMalloc(&c->d_tri, t4.size() * sizeof(float)));
+    RT_HIP(hipMemcpy(c->d_tri, t4.data(), t4.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (!c->d_material) {  // no spheres uploaded yet: an empty sphere set
+    RT_HIP(hipMalloc(&c->d_geom, sizeof(float4)));
+    RT_HIP(hipMalloc(&c->d_material, 3 * sizeof(float4)));
+    c->n_spheres = 0;
+  }
+  RT_HIP(hipMemcpy(c->d_material + 3 * (size_t)c->n_spheres, c->mesh_material, sizeof c->mesh_material,
+                   hipMemcpyHostToDevice));
+  int rc = rebuild_accel(c);
+  if (rc != RT_OK) return rc;
   c->have_scene = true;
   return RT_OK;
 }

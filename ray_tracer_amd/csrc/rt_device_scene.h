@@ -46,14 +46,18 @@ constexpr int kBvhStackEntries = 32;  // traversal stack entries per lane (>= tr
 constexpr int kMaxLargeSpheres = 16;  // oversized spheres tested outside the tree
 constexpr int32_t kNullLeaf = (int32_t)0x80000000;  // leaf slot of a sphere kept out of the tree
 
+// Primitive ids: spheres 0 .. n_spheres-1, then the triangles of the mesh.
 struct Scene {
   const float4 *geom;       // per sphere: centre.xyz, radius*radius   (original order)
-  const float4 *material;   // per sphere: colour, emission, specular  (3 x float4)
+  const float4 *material;   // colour, emission, specular (3 x float4) per sphere, then one
+                            // entry for the whole mesh at index n_spheres
   uint32_t n_spheres;
+  const float4 *tri;        // per triangle: v0, v1, v2 (3 x float4); null without a mesh
+  uint32_t n_tris;
   // LBVH (null when brute force is used)
-  const BvhNode *nodes;     // n_spheres-1 internal nodes, root = 0
-  const uint32_t *sorted_prim;  // leaf position -> original sphere index
-  const float4 *sorted_geom;    // geom[] permuted into leaf order
+  const BvhNode *nodes;     // n_prims-1 internal nodes, root = 0
+  const uint32_t *sorted_prim;  // leaf position -> primitive id
+  const float4 *sorted_geom;    // geom[] permuted into leaf order (sphere leaves only)
   const float4 *large_geom;     // oversized spheres, tested before the tree
   const uint32_t *large_prim;
   uint32_t n_large;

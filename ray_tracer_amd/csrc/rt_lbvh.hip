@@ -1,4 +1,4 @@
-// Linear BVH over spheres, built on the GPU.
+// Linear BVH over spheres and mesh triangles, built on the GPU.
 //
 //   1. leaf boxes (inflated, see below) + bounds of the centres       k_leaf_boxes
 //   2. 30-bit Morton code of each centre                              k_morton
@@ -74,38 +74,70 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// cr = centre.xyz, radius.  cbounds = 6 ordered words: min xyz, max xyz of the centres.
-__global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restrict__ cr, uint32_t n,
+// Primitive i < n_spheres is sphere i (cr = centre.xyz, radius); the others are the mesh
+// triangles (tri = v0, v1, v2 per triangle).  cbounds = 6 ordered words: min xyz, max xyz of
+// the box centres of the primitives that go into the tree.
+__global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restrict__ cr,
+                                                         uint32_t n_spheres,
+                                                         const float4 *__restrict__ tri, uint32_t n,
                                                          BoxParams bp, float4 *__restrict__ leaf_lo,
                                                          float4 *__restrict__ leaf_hi,
                                                          uint32_t *cbounds) {
   float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-    const float4 s = cr[i];
-    const float c[3] = {s.x, s.y, s.z};
-    float d2 = 0.f;
+    float lo[3], hi[3], c[3];
+    if (i < n_spheres) {
+      const float4 s = cr[i];
+      const float r = fabsf(s.w);
+      if (r > bp.large_radius) {  // null leaf: empty box, flagged in .w
+        leaf_lo[i] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 1.f);
+        leaf_hi[i] = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
+        continue;
+      }
+      c[0] = s.x; c[1] = s.y; c[2] = s.z;
+      float d2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float far = fmaxf(fabsf(c[k] - bp.blo[k]), fabsf(c[k] - bp.bhi[k]));
-      d2 += far * far;
-    }
-    const float r = fabsf(s.w);
-    if (r > bp.large_radius) {  // null leaf: empty box, flagged in .w
-      leaf_lo[i] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 1.f);
-      leaf_hi[i] = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
-      continue;
+      for (int k = 0; k < 3; ++k) {
+        const float far = fmaxf(fabsf(c[k] - bp.blo[k]), fabsf(c[k] - bp.bhi[k]));
+        d2 += far * far;
+      }
+      float alpha = 4.8e-7f * d2 / fmaxf(r * r, 1e-30f);
+      alpha = fminf(fmaxf(alpha, 0x1p-10f), 0.5f);
+      const float h = r + r * alpha + 1e-30f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = c[k] - h;
+        hi[k] = c[k] + h;
+      }
+    } else {
+      // a triangle's float test errs by ~eps * (distance to the ray origin) at its edges
+      const float4 *T = tri + 3u * (i - n_spheres);
+      const float4 a = T[0], b = T[1], cc = T[2];
+      const float v[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {cc.x, cc.y, cc.z}};
+      float d2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(fminf(v[0][k], v[1][k]), v[2][k]);
+        hi[k] = fmaxf(fmaxf(v[0][k], v[1][k]), v[2][k]);
+        c[k] = 0.5f * (lo[k] + hi[k]);
+        const float far = fmaxf(fabsf(c[k] - bp.blo[k]), fabsf(c[k] - bp.bhi[k])) + (hi[k] - lo[k]);
+        d2 += far * far;
+      }
+      const float m = 4.0e-6f * sqrtf(d2) + 1e-30f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lo[k] -= m;
+        hi[k] += m;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       mn[k] = fminf(mn[k], c[k]);
       mx[k] = fmaxf(mx[k], c[k]);
     }
-    float alpha = 4.8e-7f * d2 / fmaxf(r * r, 1e-30f);
-    alpha = fminf(fmaxf(alpha, 0x1p-10f), 0.5f);
-    const float h = r + r * alpha + 1e-30f;
-    leaf_lo[i] = make_float4(c[0] - h, c[1] - h, c[2] - h, 0.f);
-    leaf_hi[i] = make_float4(c[0] + h, c[1] + h, c[2] + h, 0.f);
+    leaf_lo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    leaf_hi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -125,14 +157,16 @@ __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
   return v;
 }
 
-__global__ __launch_bounds__(kThreads) void k_morton(const float4 *__restrict__ cr, uint32_t n,
+__global__ __launch_bounds__(kThreads) void k_morton(const float4 *__restrict__ leaf_lo,
+                                                     const float4 *__restrict__ leaf_hi, uint32_t n,
                                                      const uint32_t *__restrict__ cbounds,
                                                      uint32_t *__restrict__ keys,
                                                      uint32_t *__restrict__ vals) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
-  const float4 s = cr[i];
-  const float c[3] = {s.x, s.y, s.z};
+  const float4 bl = leaf_lo[i], bh = leaf_hi[i];
+  float c[3] = {0.5f * (bl.x + bh.x), 0.5f * (bl.y + bh.y), 0.5f * (bl.z + bh.z)};
+  if (bl.w != 0.f) c[0] = c[1] = c[2] = 0.f;  // null leaf (empty box): any code will do
   // one scale for all axes (cubic cells): a flat scene must not spend a third of its code
   // bits slicing its thin axis
   float lo[3], ext = 0.f;
@@ -357,10 +391,13 @@ __global__ __launch_bounds__(kThreads) void k_refit(RefitView v, uint32_t pass) 
 }
 
 __global__ __launch_bounds__(kThreads) void k_permute(const float4 *__restrict__ geom,
+                                                      uint32_t n_spheres,
                                                       const uint32_t *__restrict__ sorted_prim,
                                                       float4 *__restrict__ sorted_geom, uint32_t n) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) sorted_geom[i] = geom[sorted_prim[i]];
+  if (i >= n) return;
+  const uint32_t prim = sorted_prim[i];
+  sorted_geom[i] = prim < n_spheres ? geom[prim] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 }  // namespace
@@ -409,8 +446,10 @@ void Lbvh::release() {
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
-int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, const float cam[3],
+int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spheres,
+                const float4 *d_tri, const float *h_tri9, uint32_t n_tris, const float cam[3],
                 hipStream_t stream, std::string *err) {
+  const uint32_t n = n_spheres + n_tris;
   if (n == 0) {
     if (err) *err = "empty scene";
     return -1;
@@ -462,9 +501,9 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, cons
   Work &w = *work;
 
   // ---- host prologue: (centre, radius) records and the region ray origins stay in ----------
-  std::vector<float> cr((size_t)n * 4);
+  std::vector<float> cr((size_t)std::max(n_spheres, 1u) * 4);
   double rsum = 0.0;
-  for (uint32_t i = 0; i < n; ++i) {
+  for (uint32_t i = 0; i < n_spheres; ++i) {
     const float *s = h_spheres64 + (size_t)i * 16;
     cr[4 * (size_t)i + 0] = s[0];
     cr[4 * (size_t)i + 1] = s[1];
@@ -472,21 +511,27 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, cons
     cr[4 * (size_t)i + 3] = s[3];
     rsum += std::fabs((double)s[3]);
   }
-  const float r_ordinary = (float)(8.0 * rsum / n);
+  const float r_ordinary = n_spheres ? (float)(8.0 * rsum / n_spheres) : 0.f;
   BoxParams bp;
   {
-    // oversized spheres: radius above a tenth of the diagonal of the centres' bounds
-    float clo[3] = {cr[0], cr[1], cr[2]}, chi[3] = {cr[0], cr[1], cr[2]};
-    for (uint32_t i = 1; i < n; ++i)
+    // oversized spheres: radius above a tenth of the diagonal of the bounds of all sphere
+    // centres and mesh vertices
+    float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+    for (uint32_t i = 0; i < n_spheres; ++i)
       for (int k = 0; k < 3; ++k) {
         clo[k] = std::min(clo[k], cr[4 * (size_t)i + k]);
         chi[k] = std::max(chi[k], cr[4 * (size_t)i + k]);
+      }
+    for (size_t v = 0; v < (size_t)n_tris * 3; ++v)
+      for (int k = 0; k < 3; ++k) {
+        clo[k] = std::min(clo[k], h_tri9[3 * v + k]);
+        chi[k] = std::max(chi[k], h_tri9[3 * v + k]);
       }
     double diag2 = 0.0;
     for (int k = 0; k < 3; ++k) diag2 += ((double)chi[k] - clo[k]) * ((double)chi[k] - clo[k]);
     bp.large_radius = n >= 3 ? (float)(0.1 * std::sqrt(diag2)) : 3.0e38f;
     std::vector<uint32_t> big;
-    for (uint32_t i = 0; i < n; ++i)
+    for (uint32_t i = 0; i < n_spheres; ++i)
       if (std::fabs(cr[4 * (size_t)i + 3]) > bp.large_radius) big.push_back(i);
     if (big.size() > (size_t)kMaxLargeSpheres || big.size() == n) {
       bp.large_radius = 3.0e38f;  // too many to list: everything goes into the tree
@@ -510,7 +555,12 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, cons
   }
   float rmax_small = 0.f;
   for (int k = 0; k < 3; ++k) bp.blo[k] = bp.bhi[k] = cam[k];
-  for (uint32_t i = 0; i < n; ++i) {
+  for (size_t v = 0; v < (size_t)n_tris * 3; ++v)
+    for (int k = 0; k < 3; ++k) {
+      bp.blo[k] = std::min(bp.blo[k], h_tri9[3 * v + k]);
+      bp.bhi[k] = std::max(bp.bhi[k], h_tri9[3 * v + k]);
+    }
+  for (uint32_t i = 0; i < n_spheres; ++i) {
     const float *s = &cr[4 * (size_t)i];
     if (std::fabs(s[3]) > r_ordinary) continue;
     rmax_small = std::max(rmax_small, std::fabs(s[3]));
@@ -526,15 +576,18 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, cons
 
   // ---- device build ----------------------------------------------------------------------
   BVH_HIP(hipEventRecord(w.ev0, stream));
-  BVH_HIP(hipMemcpyAsync(w.cr, cr.data(), cr.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-  BVH_HIP(hipStreamSynchronize(stream));  // cr (pageable host memory) must outlive the copy
+  if (n_spheres) {
+    BVH_HIP(hipMemcpyAsync(w.cr, cr.data(), (size_t)n_spheres * 4 * sizeof(float),
+                           hipMemcpyHostToDevice, stream));
+    BVH_HIP(hipStreamSynchronize(stream));  // cr (pageable host memory) must outlive the copy
+  }
   BVH_HIP(hipMemsetAsync(w.cbounds, 0xff, 3 * sizeof(uint32_t), stream));      // running minima
   BVH_HIP(hipMemsetAsync(w.cbounds + 3, 0x00, 3 * sizeof(uint32_t), stream));  // running maxima
   const uint32_t blocks_n = (n + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(k_leaf_boxes, dim3(std::min(blocks_n, 1024u)), dim3(kThreads), 0, stream, w.cr, n,
-                     bp, w.leaf_lo, w.leaf_hi, w.cbounds);
-  hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kThreads), 0, stream, w.cr, n, w.cbounds,
-                     w.keys[0], w.vals[0]);
+  hipLaunchKernelGGL(k_leaf_boxes, dim3(std::min(blocks_n, 1024u)), dim3(kThreads), 0, stream, w.cr,
+                     n_spheres, d_tri, n, bp, w.leaf_lo, w.leaf_hi, w.cbounds);
+  hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kThreads), 0, stream, w.leaf_lo, w.leaf_hi, n,
+                     w.cbounds, w.keys[0], w.vals[0]);
   int cur = 0;
   for (uint32_t shift = 0; shift < 32; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], n, shift, w.hist,
@@ -547,8 +600,8 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n, cons
   // sorted codes in keys[cur], sorted_prim = vals[cur]
   BVH_HIP(hipMemcpyAsync(sorted_prim, w.vals[cur], (size_t)n * sizeof(uint32_t),
                          hipMemcpyDeviceToDevice, stream));
-  hipLaunchKernelGGL(k_permute, dim3(blocks_n), dim3(kThreads), 0, stream, d_geom, sorted_prim,
-                     sorted_geom, n);
+  hipLaunchKernelGGL(k_permute, dim3(blocks_n), dim3(kThreads), 0, stream, d_geom, n_spheres,
+                     sorted_prim, sorted_geom, n);
   n_nodes = n - 1;
   height = 0;
   if (n >= 2) {

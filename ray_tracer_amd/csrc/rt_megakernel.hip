@@ -41,17 +41,15 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
         f3 o, d;
         sample_ray<STRICT>(P, base, rng, o, d);
         f3 light = mk3(0.f, 0.f, 0.f), colour = mk3(1.f, 1.f, 1.f);
+        int skip = -1;
         for (int b = 0; b < P.n_bounce; ++b) {
           Hit h;
-          if constexpr (COUNT) h = closest_hit_bvh<true>(S, o, d, stack, &cnt_nodes, &cnt_prims);
-          else h = closest_hit<BVH>(S, o, d, stack);
+          if constexpr (COUNT) h = closest_hit_bvh<true>(S, o, d, stack, skip, &cnt_nodes, &cnt_prims);
+          else h = closest_hit<BVH>(S, o, d, stack, skip);
           ++nrays;
           if (s == 0 && b == 0) id0 = h.idx;
           if (h.idx >= 0) {
-            f3 centre;
-            float4 mc, me, ms;
-            load_hit_sphere(S, h.idx, centre, mc, me, ms);
-            scatter<STRICT>(centre, mc, me, ms, h.dst, rng, o, d, light, colour);
+            skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
           } else {
             light = fma3v(environment<STRICT>(P, d), colour, light);
             break;
@@ -100,18 +98,16 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
     f3 o, d;
     sample_ray<STRICT>(P, base, rng, o, d);
     f3 light = mk3(0.f, 0.f, 0.f), colour = mk3(1.f, 1.f, 1.f);
+    int skip = -1;
 
     bool active = true;
     while (active) {
-      Hit h = closest_hit<BVH>(S, o, d, stack);
+      Hit h = closest_hit<BVH>(S, o, d, stack, skip);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        f3 centre;
-        float4 mc, me, ms;
-        load_hit_sphere(S, h.idx, centre, mc, me, ms);
-        scatter<STRICT>(centre, mc, me, ms, h.dst, rng, o, d, light, colour);
+        skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -138,6 +134,7 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
           light = mk3(0.f, 0.f, 0.f);
           colour = mk3(1.f, 1.f, 1.f);
           b = 0;
+          skip = -1;
         }
       }
     }

@@ -103,7 +103,51 @@ __device__ __forceinline__ void sphere_candidate(float4 g, int i, f3 o, f3 d, fl
   }
 }
 
-__device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d) {
+// a x b, the second product of each component fused into the difference
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+  return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+             __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+// Ray-triangle test (extension: the reference has spheres only).  Moeller-Trumbore with
+// the barycentric tests on the un-divided numerators, so only a ray that is inside the
+// triangle pays for the IEEE divide:
+//   e1 = v1-v0, e2 = v2-v0, p = d x e2, det = e1.p        (det == 0 or NaN: miss)
+//   tv = o-v0, un = tv.p, q = tv x e1, vn = d.q, tn = e2.q
+//   with s = sign(det): s*un >= 0, s*vn >= 0, s*(un+vn) <= s*det, s*tn >= 0, else miss
+//   dst = tn / det.  Both faces are hit.
+// Accepts when closer than best, or equally far with a lower primitive id (so the result
+// does not depend on the order in which primitives are visited).  best_n is the sphere
+// numerator shortcut of sphere_candidate; a triangle win invalidates it.
+__device__ __forceinline__ void triangle_candidate(const float4 *__restrict__ T, int idx, f3 o, f3 d,
+                                                   float &best_n, Hit &best) {
+  const float4 a0 = T[0], a1 = T[1], a2 = T[2];
+  const f3 v0 = mk3(a0.x, a0.y, a0.z);
+  const f3 e1 = mk3(a1.x - a0.x, a1.y - a0.y, a1.z - a0.z);
+  const f3 e2 = mk3(a2.x - a0.x, a2.y - a0.y, a2.z - a0.z);
+  const f3 p = cross(d, e2);
+  const float det = dot(e1, p);
+  if (!(det != 0.0f)) return;
+  const float s = det > 0.0f ? 1.0f : -1.0f;
+  const f3 tv = o - v0;
+  const float un = dot(tv, p);
+  if (!(un * s >= 0.0f)) return;
+  const f3 q = cross(tv, e1);
+  const float vn = dot(d, q);
+  if (!(vn * s >= 0.0f) || !((un + vn) * s <= det * s)) return;
+  const float tn = dot(e2, q);
+  if (!(tn * s >= 0.0f)) return;
+  const float t = ieee_div(tn, det);
+  if (t < best.dst || (t == best.dst && idx < best.idx)) {
+    best.dst = t;
+    best.idx = idx;
+    best_n = __builtin_inff();
+  }
+}
+
+// skip: id of the triangle the ray starts on (-1: none); a planar primitive cannot be hit
+// again by a ray that leaves it, and the test above has no epsilon.
+__device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int skip) {
   Hit best;
   best.dst = 3.402823466e+38f;
   best.idx = -1;
@@ -111,6 +155,14 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d) {
   float a = dot(d, d);
   const uint32_t n = S.n_spheres;
   for (uint32_t i = 0; i < n; ++i) sphere_candidate(S.geom[i], (int)i, o, d, a, best_n, best);
+  if (S.n_tris) {
+    if (best.idx < 0) best.idx = 0x7fffffff;
+    for (uint32_t t = 0; t < S.n_tris; ++t) {
+      const int id = (int)(n + t);
+      if (id != skip) triangle_candidate(S.tri + 3u * t, id, o, d, best_n, best);
+    }
+    if (best.idx == 0x7fffffff) best.idx = -1;
+  }
   return best;
 }
 
@@ -149,15 +201,42 @@ __device__ __forceinline__ float normal_draw(uint32_t &rng) {
   return M::sqrt(M::neg2log(u2)) * M::box_cos(u1);
 }
 
-// On a hit: new origin and direction, emitted light added, throughput updated.
-// centre is the hit sphere's centre, m its three material vectors.
+// Hit point, surface normal and material of primitive idx hit at distance dst.
+// Sphere: hitPoint = origin + dir*dst, normal = normalize(hitPoint - centre) (:164-165).
+// Triangle: normal = normalize(e1 x e2) turned against the ray.  Returns the id the next
+// segment must skip (the triangle itself) or -1.
+__device__ __forceinline__ int hit_surface(const Scene &S, int idx, float dst, f3 o, f3 d, f3 &p,
+                                           f3 &n, float4 &m_colour, float4 &m_emission,
+                                           float4 &m_specular) {
+  p = fma3(d, dst, o);
+  int mat, skip;
+  if ((uint32_t)idx < S.n_spheres) {
+    const float4 g = S.geom[idx];
+    n = ieee_normalize(p - mk3(g.x, g.y, g.z));
+    mat = idx;
+    skip = -1;
+  } else {
+    const float4 *T = S.tri + 3u * ((uint32_t)idx - S.n_spheres);
+    const float4 a0 = T[0], a1 = T[1], a2 = T[2];
+    n = ieee_normalize(cross(mk3(a1.x - a0.x, a1.y - a0.y, a1.z - a0.z),
+                             mk3(a2.x - a0.x, a2.y - a0.y, a2.z - a0.z)));
+    if (dot(n, d) > 0.0f) n = mk3(-n.x, -n.y, -n.z);
+    mat = (int)S.n_spheres;
+    skip = idx;
+  }
+  m_colour = S.material[3 * mat + 0];
+  m_emission = S.material[3 * mat + 1];
+  m_specular = S.material[3 * mat + 2];
+  return skip;
+}
+
+// On a hit at point p with normal n: new origin and direction, emitted light added,
+// throughput updated (:199-213).
 template <bool STRICT>
-__device__ __forceinline__ void scatter(f3 centre, float4 m_colour, float4 m_emission,
-                                        float4 m_specular, float dst, uint32_t &rng, f3 &o, f3 &d,
+__device__ __forceinline__ void scatter(f3 p, f3 n, float4 m_colour, float4 m_emission,
+                                        float4 m_specular, uint32_t &rng, f3 &o, f3 &d,
                                         f3 &light, f3 &colour) {
   using M = Math<STRICT>;
-  f3 p = fma3(d, dst, o);                    // hitPoint = origin + dir*dst (:164)
-  f3 n = ieee_normalize(p - centre);         // (:165)
   o = p;                                     // (:201)
   float x = normal_draw<STRICT>(rng);        // randomDirection (:127-132)
   float y = normal_draw<STRICT>(rng);

@@ -51,8 +51,19 @@ __device__ __forceinline__ float slab_entry(const float lo[3], const float hi[3]
 // bytes-per-segment figure; the search itself is identical.
 // `stack` points at kBvhStack * kBlockThreads ints of LDS owned by the calling kernel
 // (entry-major); it is scratch, so a kernel may reuse that memory between searches.
+// leaf at sorted position pos: a sphere (geometry in leaf order) or a triangle of the mesh
+__device__ __forceinline__ void leaf_candidate(const Scene &S, int pos, f3 o, f3 d, float a, int skip,
+                                               float &best_n, Hit &best) {
+  const int prim = (int)S.sorted_prim[pos];
+  if ((uint32_t)prim < S.n_spheres) {
+    sphere_candidate_tie(S.sorted_geom[pos], prim, o, d, a, best_n, best);
+  } else if (prim != skip) {
+    triangle_candidate(S.tri + 3u * ((uint32_t)prim - S.n_spheres), prim, o, d, best_n, best);
+  }
+}
+
 template <bool COUNT = false>
-__device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *stack,
+__device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *stack, int skip,
                                                uint32_t *n_nodes = nullptr,
                                                uint32_t *n_prims = nullptr) {
   const int tid = threadIdx.x;
@@ -67,9 +78,9 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
     sphere_candidate_tie(S.large_geom[i], (int)S.large_prim[i], o, d, a, best_n, best);
     if constexpr (COUNT) ++*n_prims;
   }
-  if (S.n_spheres == 1u) {
+  if (S.n_spheres + S.n_tris == 1u) {
     if (S.n_large == 0u) {
-      sphere_candidate_tie(S.sorted_geom[0], (int)S.sorted_prim[0], o, d, a, best_n, best);
+      leaf_candidate(S, 0, o, d, a, skip, best_n, best);
       if constexpr (COUNT) ++*n_prims;
     }
   } else {
@@ -85,14 +96,14 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
       int c0 = nd.child0, c1 = nd.child1;
       if (t0 < __builtin_inff() && c0 < 0) {
         if (c0 != kNullLeaf) {
-          sphere_candidate_tie(S.sorted_geom[~c0], (int)S.sorted_prim[~c0], o, d, a, best_n, best);
+          leaf_candidate(S, ~c0, o, d, a, skip, best_n, best);
           if constexpr (COUNT) ++*n_prims;
         }
         t0 = __builtin_inff();
       }
       if (t1 < __builtin_inff() && c1 < 0) {
         if (c1 != kNullLeaf) {
-          sphere_candidate_tie(S.sorted_geom[~c1], (int)S.sorted_prim[~c1], o, d, a, best_n, best);
+          leaf_candidate(S, ~c1, o, d, a, skip, best_n, best);
           if constexpr (COUNT) ++*n_prims;
         }
         t1 = __builtin_inff();
@@ -116,22 +127,25 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
 
 // closest hit through whichever structure the kernel was built for
 template <bool BVH>
-__device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stack) {
-  if constexpr (BVH) return closest_hit_bvh(S, o, d, stack);
-  else return closest_hit_brute(S, o, d);
+__device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stack, int skip) {
+  if constexpr (BVH) return closest_hit_bvh(S, o, d, stack, skip);
+  else return closest_hit_brute(S, o, d, skip);
 }
 
 // LDS words a kernel must provide for the traversal stack (1 keeps the array legal)
 template <bool BVH>
 constexpr int bvh_stack_words() { return BVH ? kBvhStack * kBlockThreads : 1; }
 
-__device__ __forceinline__ void load_hit_sphere(const Scene &S, int idx, f3 &centre, float4 &mc,
-                                                float4 &me, float4 &ms) {
-  float4 g = S.geom[idx];
-  centre = mk3(g.x, g.y, g.z);
-  mc = S.material[3 * idx + 0];
-  me = S.material[3 * idx + 1];
-  ms = S.material[3 * idx + 2];
+// One hit bounce: surface at the hit, then the shader's scatter.  Returns the primitive the
+// next segment must skip.
+template <bool STRICT>
+__device__ __forceinline__ int shade_hit(const Scene &S, Hit h, uint32_t &rng, f3 &o, f3 &d,
+                                         f3 &light, f3 &colour) {
+  f3 p, n;
+  float4 mc, me, ms;
+  const int skip = hit_surface(S, h.idx, h.dst, o, d, p, n, mc, me, ms);
+  scatter<STRICT>(p, n, mc, me, ms, rng, o, d, light, colour);
+  return skip;
 }
 
 }  // namespace rt

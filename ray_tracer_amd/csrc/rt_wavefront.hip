@@ -6,7 +6,7 @@
 // its samples, ray_tracing.comp:82-96, so the samples of one pixel cannot run side by
 // side).  Path state lives in HBM as structure-of-arrays of float4, indexed by pixel:
 //   P0 = origin.xyz, rng            P1 = dir.xyz, (sample << 16 | bounce)
-//   P2 = throughput.xyz, -          P3 = light.xyz, -
+//   P2 = throughput.xyz, skip id    P3 = light.xyz, -
 //   T  = sum over samples.xyz, -    H  = (dst, sphere index) of the last extend
 //   alive = 1 while the pixel still has samples to trace in this frame
 // One iteration = two launches:
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_wf_init(Params P, uint32_t frame, WfVie
   sample_ray<STRICT>(P, pixel_direction(P, px, py), rng, o, d);
   V.P0[i] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
   V.P1[i] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));
-  V.P2[i] = make_float4(1.f, 1.f, 1.f, 0.f);
+  V.P2[i] = make_float4(1.f, 1.f, 1.f, __int_as_float(-1));
   V.P3[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   V.T[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   V.alive[i] = 1;
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
     is_hit[k] = is_miss[k] = false;
     if (pix[k] < n_pixels && V.alive[pix[k]]) {
       const float4 p0 = V.P0[pix[k]], p1 = V.P1[pix[k]];
-      const Hit h = closest_hit<BVH>(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), stack);
+      const int skip = S.n_tris ? __float_as_int(V.P2[pix[k]].w) : -1;
+      const Hit h = closest_hit<BVH>(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), stack, skip);
       V.H[pix[k]] = make_float2(h.dst, __int_as_float(h.idx));
       if (__float_as_uint(p1.w) == 0u) ids[pix[k]] = h.idx;  // sample 0, bounce 0
       is_hit[k] = h.idx >= 0;
@@ -152,7 +153,7 @@ __device__ __forceinline__ bool path_end(const Params &P, const WfView &V, const
   sample_ray<STRICT>(P, pixel_direction(P, px, py), rng, o, d);
   V.P0[pix] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
   V.P1[pix] = make_float4(d.x, d.y, d.z, __uint_as_float(s << 16));
-  V.P2[pix] = make_float4(1.f, 1.f, 1.f, 0.f);
+  V.P2[pix] = make_float4(1.f, 1.f, 1.f, __int_as_float(-1));
   V.P3[pix] = make_float4(0.f, 0.f, 0.f, 0.f);
   return true;
 }
@@ -181,16 +182,17 @@ __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, u
         uint32_t s = sb >> 16, b = sb & 0xffffu;
         f3 o = mk3(p0.x, p0.y, p0.z), d = mk3(p1.x, p1.y, p1.z);
         f3 colour = mk3(p2.x, p2.y, p2.z), light = mk3(p3.x, p3.y, p3.z);
-        const float4 g = S.geom[idx];
-        scatter<STRICT>(mk3(g.x, g.y, g.z), S.material[3 * idx], S.material[3 * idx + 1],
-                        S.material[3 * idx + 2], hrec.x, rng, o, d, light, colour);
+        Hit h;
+        h.dst = hrec.x;
+        h.idx = idx;
+        const int skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
         ++b;
         if (b >= (uint32_t)P.n_bounce) {
           path_end<STRICT>(P, V, O, frame, px, rng, s, light);
         } else {
           V.P0[px] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
           V.P1[px] = make_float4(d.x, d.y, d.z, __uint_as_float((s << 16) | b));
-          V.P2[px] = make_float4(colour.x, colour.y, colour.z, 0.f);
+          V.P2[px] = make_float4(colour.x, colour.y, colour.z, __int_as_float(skip));
           V.P3[px] = make_float4(light.x, light.y, light.z, 0.f);
         }
       }
@@ -246,15 +248,14 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
     f3 colour = mk3(p2.x, p2.y, p2.z), light = mk3(p3.x, p3.y, p3.z);
     f3 total = mk3(t.x, t.y, t.z);
     int id0 = -2;
+    int skip = __float_as_int(p2.w);
     while (true) {
-      const Hit h = closest_hit<BVH>(S, o, d, stack);
+      const Hit h = closest_hit<BVH>(S, o, d, stack, skip);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        const float4 g = S.geom[h.idx];
-        scatter<STRICT>(mk3(g.x, g.y, g.z), S.material[3 * h.idx], S.material[3 * h.idx + 1],
-                        S.material[3 * h.idx + 2], h.dst, rng, o, d, light, colour);
+        skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
         light = mk3(0.f, 0.f, 0.f);
         colour = mk3(1.f, 1.f, 1.f);
         b = 0;
+        skip = -1;
       }
     }
     float4 acc = O.accum[pix];

@@ -27,6 +27,16 @@ L.rto_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uin
                          C.c_void_p, C.c_void_p, C.c_int]
 
 
+class Mesh(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("n_vertices", C.c_uint32), ("indices", C.c_void_p),
+                ("n_triangles", C.c_uint32), ("material", C.c_void_p)]
+
+
+L.rto_render_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Mesh), C.c_uint32,
+                              C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+
+
 class Camera(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "fov", "near_", "far_", "pitch", "yaw", "aspect_ratio", "distance", "viewport_width",
@@ -110,8 +120,10 @@ def pm(name, x, y=None):
 
 
 def render(ubo, spheres, width, height, first_frame=0, n_frames=1, stride=1,
-           math_mode=MATH_PORTABLE, accum_mode=ACCUM_GAMMA, threads=8, accum=None, rgba8=None):
-    """Returns dict(accum, rgba8, ids, rays).  accum/rgba8 may be passed in to continue."""
+           math_mode=MATH_PORTABLE, accum_mode=ACCUM_GAMMA, threads=8, accum=None, rgba8=None,
+           mesh=None):
+    """Returns dict(accum, rgba8, ids, rays).  accum/rgba8 may be passed in to continue.
+    mesh = (vertices (n,3) float32, indices (m,3) uint32, material (12,) float32) or None."""
     ubo = np.ascontiguousarray(ubo, dtype=np.float32)
     spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 16)
     if accum is None:
@@ -120,11 +132,18 @@ def render(ubo, spheres, width, height, first_frame=0, n_frames=1, stride=1,
         rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
     ids = np.full((height, width), -1, dtype=np.int32)
     rays = C.c_uint64(0)
-    rc = L.rto_render(ubo.ctypes.data_as(C.c_void_p), spheres.ctypes.data_as(C.c_void_p),
-                      spheres.shape[0], width, height, first_frame, n_frames, stride, math_mode,
-                      accum_mode, accum.ctypes.data_as(C.c_void_p),
-                      rgba8.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
-                      C.byref(rays), threads)
+    mptr = None
+    if mesh is not None:
+        v = np.ascontiguousarray(mesh[0], dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(mesh[1], dtype=np.uint32).reshape(-1, 3)
+        m = np.ascontiguousarray(mesh[2], dtype=np.float32).reshape(12)
+        mstruct = Mesh(v.ctypes.data, v.shape[0], i.ctypes.data, i.shape[0], m.ctypes.data)
+        mptr = C.byref(mstruct)
+    rc = L.rto_render_mesh(ubo.ctypes.data_as(C.c_void_p), spheres.ctypes.data_as(C.c_void_p),
+                           spheres.shape[0], mptr, width, height, first_frame, n_frames, stride,
+                           math_mode, accum_mode, accum.ctypes.data_as(C.c_void_p),
+                           rgba8.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                           C.byref(rays), threads)
     assert rc == 0
     return dict(accum=accum, rgba8=rgba8, ids=ids, rays=int(rays.value))
 

@@ -404,3 +404,74 @@ def test_scene_and_params_can_change_between_renders(oracle):
             assert r.stats().bvh_nodes == (n - 1 if n > 16 else 0)
             assert np.array_equal(r.read_primary_ids(), want["ids"])
             assert np.array_equal(_bits(r.read_accum()), _bits(want["accum"]))
+
+
+# ---------------------------------------------------------------- triangle meshes (extension)
+def gpu_render_mesh(ubo, spheres, mesh, w, h, mode, flags, first=0, n=1, stride=1):
+    with rt.Renderer(w, h, mode=mode, flags=flags) as r:
+        r.set_params(ubo)
+        r.set_spheres(spheres)
+        r.set_mesh(*mesh)
+        r.render(first, n, stride)
+        r.sync()
+        st = r.stats()
+        return dict(accum=r.read_accum(), rgba8=r.read_rgba8(), ids=r.read_primary_ids(),
+                    rays=int(st.rays), stats=st)
+
+
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT])
+@pytest.mark.parametrize("accel", [rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH])
+def test_mesh_and_spheres_bit_exact(oracle, mode, accel):
+    """Small terrain (18 x 18 vertices, 578 triangles) under the reference's three spheres."""
+    w, h = 128, 72
+    ubo = rt.make_ubo(w, h, 2, 8)
+    sph = rt.default_scene()
+    sph[2, :4] = (0, -1000, -5, 1)          # shrink the ground sphere out of the way
+    v, i = rt.terrain_mesh(18, phase=0.3, size=30.0, depth=-14.0)
+    mat = rt.matte(0.7, 0.6, 0.4, smoothness=0.6, specular_probability=0.3)
+    want = oracle.render(ubo, sph, w, h, 0, 2, 1, mesh=(v, i, mat))
+    got = gpu_render_mesh(ubo, sph, (v, i, mat), w, h, mode, rt.FLAG_STRICT_MATH | accel, 0, 2, 1)
+    assert int((want["ids"] >= 3).sum()) > 1000
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+    assert np.array_equal(got["rgba8"], want["rgba8"])
+
+
+def test_mesh_only_scene_and_removal(oracle):
+    w, h = 96, 64
+    ubo = rt.make_ubo(w, h, 1, 4)
+    v, i = rt.terrain_mesh(12, size=20.0, depth=-12.0)
+    mat = rt.matte(0.3, 0.8, 0.3)
+    none = np.zeros((0, 16), np.float32)
+    want = oracle.render(ubo, none, w, h, mesh=(v, i, mat))
+    with rt.Renderer(w, h, flags=rt.FLAG_STRICT_MATH) as r:
+        r.set_params(ubo)
+        r.set_mesh(v, i, mat)                      # no rt_set_spheres at all
+        r.render(0, 1, 1)
+        assert np.array_equal(r.read_primary_ids(), want["ids"])
+        assert np.array_equal(_bits(r.read_accum()), _bits(want["accum"]))
+        assert r.stats().bvh_nodes == i.shape[0] - 1
+        r.clear()
+        r.set_mesh(v, np.zeros((0, 3), np.uint32), mat)   # remove it again: sky only
+        r.render(0, 1, 1)
+        assert (r.read_primary_ids() == -1).all()
+        with pytest.raises(rt.RtError):
+            r.set_mesh(v, np.array([[0, 1, 999999]], np.uint32), mat)
+
+
+def test_large_mesh_kernels_agree():
+    """200k triangles: the three kernel organisations trace identical paths through the LBVH."""
+    w, h = 480, 270
+    ubo = rt.make_ubo(w, h, 2, 8)
+    v, i = rt.terrain_mesh(318)
+    mat = rt.matte(0.6, 0.6, 0.6, smoothness=0.8, specular_probability=0.2)
+    sph = rt.default_scene()[:2]
+    a = gpu_render_mesh(ubo, sph, (v, i, mat), w, h, rt.MODE_MEGAKERNEL, 0)
+    b = gpu_render_mesh(ubo, sph, (v, i, mat), w, h, rt.MODE_MEGAKERNEL_NESTED, 0)
+    c = gpu_render_mesh(ubo, sph, (v, i, mat), w, h, rt.MODE_WAVEFRONT, 0)
+    assert a["stats"].bvh_nodes == i.shape[0] + 2 - 1
+    assert int((a["ids"] >= 2).sum()) > w * h // 5
+    for other in (b, c):
+        assert np.array_equal(a["ids"], other["ids"]) and a["rays"] == other["rays"]
+        assert np.array_equal(_bits(a["accum"]), _bits(other["accum"]))

@@ -201,3 +201,54 @@ def test_portable_kernels_special_values(oracle):
     assert L.rto_pm_pow(0.0, 0.35) == 0.0 and L.rto_pm_pow(1.0, 0.35) == 1.0
     assert np.isnan(L.rto_pm_pow(0.0, 0.0))
     assert L.rto_pm_cos(0.0) == 1.0 and L.rto_pm_sin(0.0) == 0.0
+
+
+# ---------------------------------------------------------------- triangles (extension)
+def _quad(z=-4.0, half=1.0):
+    v = np.array([[-half, -half, z], [half, -half, z], [half, half, z], [-half, half, z]], np.float32)
+    i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    return v, i
+
+
+def test_triangle_quad_census_and_colour(oracle):
+    """A 2x2 quad at z = -4 facing the camera covers ndc |x| <= 0.25 / (4/3), |y| <= 0.25:
+    151 x 151 pixels of the 800x608 window (viewport 800x600); with an emissive material and
+    one bounce the pixel colour is sqrt(emission)."""
+    ubo = oracle.default_ubo()
+    ubo[40], ubo[41], ubo[66], ubo[67] = 1, 1, 0, 0
+    mat = np.array([0.8, 0.8, 0.8, 0, 0.5, 0.25, 1.0, 1.0, 1, 1, 1, 0], np.float32)
+    none = np.zeros((0, 16), np.float32)
+    r = oracle.render(ubo, none, 800, 608, mesh=(*_quad(), mat))
+    ids = r["ids"]
+    assert int((ids >= 0).sum()) == 151 * 151
+    assert set(np.unique(ids)) == {-1, 0, 1}
+    ys, xs = np.nonzero(ids >= 0)
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (325, 475, 225, 375)
+    assert tuple(r["accum"][300, 400, :3]) == (np.sqrt(np.float32(0.5)), 0.5, 1.0)
+    # behind a sphere the quad is hidden; triangle ids follow the sphere ids
+    sph = oracle.default_spheres()[:1].copy()
+    sph[0, :4] = (0, 0, -3, 0.5)
+    r2 = oracle.render(ubo, sph, 800, 608, mesh=(*_quad(), mat))
+    assert r2["ids"][300, 400] == 0 and r2["ids"][300, 330] in (1, 2)
+    # the back face is hit too (winding reversed)
+    v, i = _quad()
+    r3 = oracle.render(ubo, none, 800, 608, mesh=(v, i[:, ::-1].copy(), mat))
+    assert np.array_equal(r3["ids"] >= 0, ids >= 0)
+
+
+def test_triangle_floor_does_not_hit_itself(oracle):
+    """Paths that bounce off a floor quad leave it: with only the floor in the scene every
+    path is primary hit or miss followed by at most one escape, so rays <= 2 per sample."""
+    w, h, spp = 64, 48, 4
+    cam = oracle.camera_create(90.0, 1.0, 0.01, 10000.0)
+    cam.viewport_width, cam.viewport_height = float(w), float(h)
+    ubo = oracle.default_ubo(cam)
+    ubo[40], ubo[41] = spp, 25
+    v = np.array([[-50, -1, 10], [50, -1, 10], [50, -1, -90], [-50, -1, -90]], np.float32)
+    i = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    mat = np.array([0.5, 0.5, 0.5, 0, 0, 0, 0, 0, 1, 1, 1, 0], np.float32)
+    r = oracle.render(ubo, np.zeros((0, 16), np.float32), w, h, mesh=(v, i, mat))
+    hits = int((r["ids"] >= 0).sum())
+    assert hits > 0
+    assert r["rays"] <= 2 * w * h * spp
+    assert r["rays"] > w * h * spp
