@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -65,7 +66,7 @@ struct rt_ctx {
 
   float4 *d_tri = nullptr;       // v0, v1, v2 per mesh triangle
   uint32_t n_tris = 0;
-  std::vector<float> h_tri9;     // the same, 9 floats per triangle (for rebuilds)
+  float mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0};  // bounds of the mesh vertices
   float mesh_material[12] = {0};
 
   rt::Lbvh bvh;                  // device LBVH + build workspace
@@ -153,8 +154,8 @@ int rebuild_accel(rt_ctx *c) {
   std::string err;
   const float cam[3] = {c->have_params ? c->P.cam_x : 0.f, c->have_params ? c->P.cam_y : 0.f,
                         c->have_params ? c->P.cam_z : 0.f};
-  int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), c->n_spheres, c->d_tri, c->h_tri9.data(),
-                        c->n_tris, cam, c->stream, &err);
+  int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), c->n_spheres, c->d_tri, c->mesh_lo,
+                        c->mesh_hi, c->n_tris, cam, c->stream, &err);
   if (rc != RT_OK) return fail(rc, "LBVH build: %s", err.c_str());
   if (c->bvh.height > (uint32_t)rt::kBvhStackEntries)
     return fail(RT_ERR_INVALID, "LBVH height %u exceeds the traversal stack (%d)", c->bvh.height,
@@ -368,20 +369,35 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
   if (c->d_tri) RT_HIP(hipFree(c->d_tri));
   c->d_tri = nullptr;
   c->n_tris = n_triangles;
-  c->h_tri9.resize((size_t)n_triangles * 9);
   if (material) std::memcpy(c->mesh_material, material, sizeof c->mesh_material);
+  // bounds of the vertices the triangles use (leaf boxes are sized from them)
+  for (int k = 0; k < 3; ++k) {
+    c->mesh_lo[k] = 3.0e38f;
+    c->mesh_hi[k] = -3.0e38f;
+  }
   if (n_triangles) {
-    std::vector<float> t4((size_t)n_triangles * 12, 0.f);
-    for (size_t t = 0; t < n_triangles; ++t)
-      for (int v = 0; v < 3; ++v) {
-        const float *src = vertices + 3 * (size_t)indices[3 * t + v];
+    std::vector<unsigned char> used(n_vertices, 0);
+    for (size_t k = 0; k < (size_t)n_triangles * 3; ++k) used[indices[k]] = 1;
+    for (uint32_t v = 0; v < n_vertices; ++v)
+      if (used[v])
         for (int k = 0; k < 3; ++k) {
-          c->h_tri9[9 * t + 3 * v + k] = src[k];
-          t4[12 * t + 4 * v + k] = src[k];
+          c->mesh_lo[k] = std::min(c->mesh_lo[k], vertices[3 * (size_t)v + k]);
+          c->mesh_hi[k] = std::max(c->mesh_hi[k], vertices[3 * (size_t)v + k]);
         }
-      }
-    RT_HIP(hipMalloc(&c->d_tri, t4.size() * sizeof(float)));
-    RT_HIP(hipMemcpy(c->d_tri, t4.data(), t4.size() * sizeof(float), hipMemcpyHostToDevice));
+    // indexed upload, expanded to v0,v1,v2 per triangle on the device
+    float *d_v = nullptr;
+    uint32_t *d_i = nullptr;
+    RT_HIP(hipMalloc(&d_v, (size_t)n_vertices * 3 * sizeof(float)));
+    RT_HIP(hipMalloc(&d_i, (size_t)n_triangles * 3 * sizeof(uint32_t)));
+    RT_HIP(hipMalloc(&c->d_tri, (size_t)n_triangles * 3 * sizeof(float4)));
+    hipError_t e = hipMemcpy(d_v, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = hipMemcpy(d_i, indices, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt::launch_expand_triangles(d_v, d_i, n_triangles, c->d_tri, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_v);
+    hipFree(d_i);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_set_mesh: %s", hipGetErrorString(e));
   }
   if (!c->d_material) {  // no spheres uploaded yet: an empty sphere set
     RT_HIP(hipMalloc(&c->d_geom, sizeof(float4)));

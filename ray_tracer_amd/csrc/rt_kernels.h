@@ -18,6 +18,8 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
 // rt_util.hip
 hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
                           uint32_t linear_accum, hipStream_t stream);
+hipError_t launch_expand_triangles(const float *vertices, const uint32_t *indices, uint32_t n_tris,
+                                   float4 *tri, hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,
                              hipStream_t stream);
 

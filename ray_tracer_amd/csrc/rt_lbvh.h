@@ -28,11 +28,11 @@ struct Lbvh {
   Work *work = nullptr;            // build workspace, kept between builds
 
   // d_geom: device (centre, r*r) per sphere; h_spheres64: the 64-byte host records;
-  // d_tri: device v0,v1,v2 (float4 each) per triangle; h_tri9: the same as 9 host floats;
+  // d_tri: device v0,v1,v2 (float4 each) per triangle; mesh_lo/hi: bounds of its vertices;
   // cam: camera position (ray origins are assumed to stay near the camera and the scene).
   int build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spheres, const float4 *d_tri,
-            const float *h_tri9, uint32_t n_tris, const float cam[3], hipStream_t stream,
-            std::string *err);
+            const float mesh_lo[3], const float mesh_hi[3], uint32_t n_tris, const float cam[3],
+            hipStream_t stream, std::string *err);
   int download(std::vector<BvhNode> *out_nodes, std::vector<uint32_t> *out_prims) const;
   void release();
 };

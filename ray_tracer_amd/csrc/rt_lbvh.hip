@@ -447,8 +447,8 @@ void Lbvh::release() {
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spheres,
-                const float4 *d_tri, const float *h_tri9, uint32_t n_tris, const float cam[3],
-                hipStream_t stream, std::string *err) {
+                const float4 *d_tri, const float mesh_lo[3], const float mesh_hi[3], uint32_t n_tris,
+                const float cam[3], hipStream_t stream, std::string *err) {
   const uint32_t n = n_spheres + n_tris;
   if (n == 0) {
     if (err) *err = "empty scene";
@@ -522,10 +522,10 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
         clo[k] = std::min(clo[k], cr[4 * (size_t)i + k]);
         chi[k] = std::max(chi[k], cr[4 * (size_t)i + k]);
       }
-    for (size_t v = 0; v < (size_t)n_tris * 3; ++v)
+    if (n_tris)
       for (int k = 0; k < 3; ++k) {
-        clo[k] = std::min(clo[k], h_tri9[3 * v + k]);
-        chi[k] = std::max(chi[k], h_tri9[3 * v + k]);
+        clo[k] = std::min(clo[k], mesh_lo[k]);
+        chi[k] = std::max(chi[k], mesh_hi[k]);
       }
     double diag2 = 0.0;
     for (int k = 0; k < 3; ++k) diag2 += ((double)chi[k] - clo[k]) * ((double)chi[k] - clo[k]);
@@ -555,10 +555,10 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
   }
   float rmax_small = 0.f;
   for (int k = 0; k < 3; ++k) bp.blo[k] = bp.bhi[k] = cam[k];
-  for (size_t v = 0; v < (size_t)n_tris * 3; ++v)
+  if (n_tris)
     for (int k = 0; k < 3; ++k) {
-      bp.blo[k] = std::min(bp.blo[k], h_tri9[3 * v + k]);
-      bp.bhi[k] = std::max(bp.bhi[k], h_tri9[3 * v + k]);
+      bp.blo[k] = std::min(bp.blo[k], mesh_lo[k]);
+      bp.bhi[k] = std::max(bp.bhi[k], mesh_hi[k]);
     }
   for (uint32_t i = 0; i < n_spheres; ++i) {
     const float *s = &cr[4 * (size_t)i];

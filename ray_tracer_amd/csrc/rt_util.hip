@@ -31,6 +31,27 @@ hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
   return hipGetLastError();
 }
 
+// indexed mesh -> v0, v1, v2 per triangle (one float4 each)
+__global__ __launch_bounds__(256) void k_expand_triangles(const float *__restrict__ vertices,
+                                                          const uint32_t *__restrict__ indices,
+                                                          uint32_t n_tris, float4 *__restrict__ tri) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= n_tris) return;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    const float *p = vertices + 3u * (size_t)indices[3u * t + v];
+    tri[3u * t + v] = make_float4(p[0], p[1], p[2], 0.f);
+  }
+}
+
+hipError_t launch_expand_triangles(const float *vertices, const uint32_t *indices, uint32_t n_tris,
+                                   float4 *tri, hipStream_t stream) {
+  if (n_tris == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_expand_triangles, dim3((n_tris + 255u) / 256u), dim3(256), 0, stream, vertices,
+                     indices, n_tris, tri);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_debug_eval(int op, const float *__restrict__ a,
                                                     const float *__restrict__ b,
                                                     float *__restrict__ out, size_t n) {
