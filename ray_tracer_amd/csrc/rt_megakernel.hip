@@ -12,6 +12,8 @@
 #include "rt_shading.h"
 #include "rt_traverse.h"
 
+#include <cstdlib>
+
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 1
 #endif
@@ -146,13 +148,202 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
   if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
 }
 
+// BVH scenes: the lanes of a wave need very different numbers of tree steps per path
+// segment, and under the one-loop-per-search structure above every lane waits for the
+// slowest search of its wave before anyone shades.  k_mega_sched keeps each lane's search
+// state (current node, stack depth, best hit) alive across loop iterations and lets the
+// WAVE choose, each iteration, which of three steps to run for the lanes that need it:
+//   inner  fetch one node, test both child boxes, descend / push / pop
+//   leaf   test one primitive, pop
+//   shade  finish the segment (surface + scatter, or environment and the next sample)
+//          and start the next search
+// The step with the most waiting lanes runs (weights below), so inner steps run with most
+// lanes busy and the expensive shade step runs for many lanes at once.  Each lane still
+// executes its own operations in the shader's order, and the closest hit does not depend on
+// visiting order (ties go to the lowest primitive id), so the results are those of
+// k_mega_nested bit for bit.
+#ifndef RT_SCHED_W_INNER
+#define RT_SCHED_W_INNER 2
+#endif
+#ifndef RT_SCHED_W_LEAF
+#define RT_SCHED_W_LEAF 5
+#endif
+#ifndef RT_SCHED_W_SHADE
+#define RT_SCHED_W_SHADE 2
+#endif
+
+// measurement builds only: -DRT_SCHED_STATS=<step> tallies, for that step, the lanes served
+// and the times it ran (x64) in the traversal counters
+#ifdef RT_SCHED_STATS
+#define RT_SCHED_TALLY(step, n)                                               \
+  if ((step) == RT_SCHED_STATS && (threadIdx.x & 63u) == 0) {                 \
+    atomicAdd(O.rays + 1, (unsigned long long)(n));                           \
+    atomicAdd(O.rays + 2, 64ull);                                             \
+  }
+#else
+#define RT_SCHED_TALLY(step, n)
+#endif
+
+constexpr int kSearchOver = (int)kNullLeaf;  // never a real child reference
+
+struct Search {
+  int node;  // >= 0 inner node, kSearchOver, otherwise ~leaf position
+  int sp;
+  float best_n, a;
+  f3 inv_d;
+  Hit best;
+};
+
+__device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search &Q) {
+  Q.best.dst = 3.402823466e+38f;
+  Q.best.idx = 0x7fffffff;
+  Q.best_n = __builtin_inff();
+  Q.a = dot(d, d);
+  Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+  for (uint32_t i = 0; i < S.n_large; ++i)
+    sphere_candidate_tie(S.large_geom[i], (int)S.large_prim[i], o, d, Q.a, Q.best_n, Q.best);
+  Q.sp = 0;
+  if (S.n_spheres + S.n_tris == 1u) Q.node = S.n_large ? kSearchOver : ~0;
+  else Q.node = 0;
+}
+
+__device__ __forceinline__ int search_pop(Search &Q, const int *stack) {
+  if (Q.sp == 0) return kSearchOver;
+  return stack[(--Q.sp) * kBlockThreads + threadIdx.x];
+}
+
+__device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search &Q, int *stack) {
+  const BvhNode nd = S.nodes[Q.node];
+  const float limit = __builtin_fmaf(Q.best.dst, 1.0e-4f, Q.best.dst);
+  const float t0 = slab_entry(nd.lo0, nd.hi0, o, Q.inv_d, limit);
+  const float t1 = slab_entry(nd.lo1, nd.hi1, o, Q.inv_d, limit);
+  const int c0 = nd.child0, c1 = nd.child1;
+  const bool go0 = t0 < __builtin_inff() && c0 != (int)kNullLeaf;
+  const bool go1 = t1 < __builtin_inff() && c1 != (int)kNullLeaf;
+  if (go0 && go1) {
+    const bool first0 = t0 <= t1;
+    stack[(Q.sp++) * kBlockThreads + threadIdx.x] = first0 ? c1 : c0;
+    Q.node = first0 ? c0 : c1;
+  } else if (go0 || go1) {
+    Q.node = go0 ? c0 : c1;
+  } else {
+    Q.node = search_pop(Q, stack);
+  }
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
+  __shared__ int stack[kBvhStack * kBlockThreads];
+  uint32_t px, py;
+  pixel_of_thread(px, py);
+  uint32_t nrays = 0;
+  bool active = px < P.width && py < P.height && F.count;
+  const size_t pix = active ? (size_t)py * P.width + px : 0;
+  const f3 base = pixel_direction(P, px, py);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  uchar4 img = make_uchar4(0, 0, 0, 0);
+  if (active) {
+    acc = O.accum[pix];
+    img = O.rgba8[pix];
+  }
+  int id0 = -1;
+  uint32_t fi = 0;
+  uint32_t frame = F.first;
+  uint32_t rng = pixel_seed(P, px, py, frame);
+  f3 total = mk3(0.f, 0.f, 0.f);
+  int s = 0, b = 0;
+  f3 o, d;
+  sample_ray<STRICT>(P, base, rng, o, d);
+  f3 light = mk3(0.f, 0.f, 0.f), colour = mk3(1.f, 1.f, 1.f);
+  int skip = -1;
+  Search Q;
+  search_begin(S, o, d, Q);
+
+  while (true) {
+    const bool want_inner = active && Q.node >= 0;
+    const bool want_shade = active && Q.node == kSearchOver;
+    const bool want_leaf = active && !want_inner && !want_shade;
+    const int n_inner = __builtin_popcountll(__ballot(want_inner));
+    const int n_leaf = __builtin_popcountll(__ballot(want_leaf));
+    const int n_shade = __builtin_popcountll(__ballot(want_shade));
+    if (n_inner + n_leaf + n_shade == 0) break;
+    const int w_inner = n_inner * RT_SCHED_W_INNER, w_leaf = n_leaf * RT_SCHED_W_LEAF,
+              w_shade = n_shade * RT_SCHED_W_SHADE;
+    if (w_inner >= w_leaf && w_inner >= w_shade) {
+      RT_SCHED_TALLY(1, n_inner);
+      if (want_inner) search_inner_step(S, o, Q, stack);
+    } else if (w_leaf >= w_shade) {
+      RT_SCHED_TALLY(2, n_leaf);
+      if (want_leaf) {
+        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best_n, Q.best);
+        Q.node = search_pop(Q, stack);
+      }
+    } else {
+      RT_SCHED_TALLY(3, n_shade);
+      if (!want_shade) continue;
+      Hit h = Q.best;
+      if (h.idx == 0x7fffffff) h.idx = -1;
+      ++nrays;
+      if (s == 0 && b == 0) id0 = h.idx;
+      bool path_done;
+      if (h.idx >= 0) {
+        skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
+        ++b;
+        path_done = b >= P.n_bounce;
+      } else {
+        light = fma3v(environment<STRICT>(P, d), colour, light);
+        path_done = true;
+      }
+      if (path_done) {
+        total = total + light;
+        ++s;
+        if (s >= P.n_spp) {
+          frame_epilogue(P, total, (float)frame, O.linear_accum, acc, img);
+          ++fi;
+          if (fi >= F.count) {
+            active = false;
+          } else {
+            frame += F.stride;
+            rng = pixel_seed(P, px, py, frame);
+            total = mk3(0.f, 0.f, 0.f);
+            s = 0;
+          }
+        }
+        if (active) {
+          sample_ray<STRICT>(P, base, rng, o, d);
+          light = mk3(0.f, 0.f, 0.f);
+          colour = mk3(1.f, 1.f, 1.f);
+          b = 0;
+          skip = -1;
+        }
+      }
+      if (active) {
+        search_begin(S, o, d, Q);
+      } else {
+        O.accum[pix] = acc;
+        O.rgba8[pix] = img;
+        O.ids[pix] = id0;
+      }
+    }
+  }
+  uint32_t wsum = wave_sum_u32(nrays);
+  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+}
+
 template <bool STRICT, bool BVH>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
                                 const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
   dim3 block(256, 1, 1);
+  // k_mega_regen and k_mega_sched need at least one sample and one bounce
+  static const bool sched = [] {
+    const char *e = getenv("RT_MEGA_SCHED");
+    return !(e && e[0] == '0');
+  }();
   if (nested)
     hipLaunchKernelGGL((k_mega_nested<STRICT, BVH>), grid, block, 0, stream, P, S, F, O);
+  else if (BVH && sched)
+    hipLaunchKernelGGL((k_mega_sched<STRICT>), grid, block, 0, stream, P, S, F, O);
   else
     hipLaunchKernelGGL((k_mega_regen<STRICT, BVH>), grid, block, 0, stream, P, S, F, O);
   return hipGetLastError();
