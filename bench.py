@@ -8,7 +8,10 @@ accumulation image, render one 64-spp frame into it, (N > 1: sum the N accumulat
 images onto rank 0 with one RCCL reduce over xGMI,) resolve to the 8-bit image.  With
 N GPUs rank r renders frame index step*N + r -- the sample-wise split whose frames
 carry the shader's own per-frame RNG streams -- so per-GPU work is fixed (weak
-scaling) and every step yields an N*64-spp image on rank 0.
+scaling) and every step yields an N*64-spp image on rank 0.  For N > 1 each rank keeps
+two accumulation images: the reduce of step i runs on RCCL's stream while step i+1 is
+traced into the other image, and rank 0 resolves step i when its sum has landed; all
+K renders, K reduces and K resolves lie inside the timed region.
 
 Prints ONE JSON line on rank 0.  Launch for N > 1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -85,6 +88,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["megakernel", "wavefront", "nested"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--images-in-flight", type=int, default=0,
+                    help="accumulation images per rank (default: 2 when N > 1, else 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,7 +97,7 @@ def main() -> None:
     import torch.distributed as dist
 
     import ray_tracer_amd as rt
-    from ray_tracer_amd.distributed import frame_partition, reduce_accumulation
+    from ray_tracer_amd.distributed import finish_reduce, frame_partition, start_reduce
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,41 +118,65 @@ def main() -> None:
     spheres = rt.default_scene()
     n_spheres = spheres.shape[0]
 
-    # the accumulation image lives in a torch tensor so RCCL can reduce it in place
-    accum = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+    # the accumulation images live in torch tensors so RCCL can reduce them in place
+    n_buf = args.images_in_flight if args.images_in_flight > 0 else (2 if world > 1 else 1)
     stream = torch.cuda.current_stream(dev)
-    r = rt.Renderer(WIDTH, HEIGHT, mode=mode, flags=0, device=local_rank,
-                    stream=stream.cuda_stream, accum_buffer=accum.data_ptr())
-    r.set_params(ubo)
-    r.set_spheres(spheres)
+    accums, renderers = [], []
+    for _ in range(n_buf):
+        a = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+        rr = rt.Renderer(WIDTH, HEIGHT, mode=mode, flags=0, device=local_rank,
+                         stream=stream.cuda_stream, accum_buffer=a.data_ptr())
+        rr.set_params(ubo)
+        rr.set_spheres(spheres)
+        accums.append(a)
+        renderers.append(rr)
+    in_flight = [False] * n_buf
+    pending = [None] * n_buf
+
+    def retire(k: int) -> None:
+        """finish the step that last used image k: its sum, then rank 0's 8-bit image"""
+        if in_flight[k]:
+            finish_reduce(pending[k])
+            if rank == 0:
+                renderers[k].resolve()
+            in_flight[k], pending[k] = False, None
 
     def step(i: int) -> None:
-        accum.zero_()
+        k = i % n_buf
+        retire(k)
+        accums[k].zero_()
         first, count, stride = frame_partition(i * world, world, rank, world)
-        r.render(first, count, stride)
-        reduce_accumulation(accum, dst=0)
-        if rank == 0:
-            r.resolve()
+        renderers[k].render(first, count, stride)
+        pending[k] = start_reduce(accums[k], dst=0)
+        in_flight[k] = True
+        if n_buf == 1:
+            retire(k)
 
     def fence() -> None:
+        for k in range(n_buf):
+            retire(k)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def totals():
+        st = [rr.stats() for rr in renderers]
+        return sum(s.rays for s in st), sum(s.total_render_ms for s in st)
+
     for i in range(args.warmup):
         step(i)
     fence()
-    st0 = r.stats()
+    rays0, ms0 = totals()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    st1 = r.stats()
+    rays1, ms1 = totals()
 
-    rays = float(st1.rays - st0.rays)
-    kernel_ms = float(st1.total_render_ms - st0.total_render_ms)
+    rays = float(rays1 - rays0)
+    kernel_ms = float(ms1 - ms0)
 
     # configs[1] asks for "megakernel vs wavefront": time a few frames of the other
     # organisation outside the timed region (rank 0 of a single-GPU run only)
@@ -198,7 +227,8 @@ def main() -> None:
                             "(BASELINE.json configs[1])",
                 "mode": args.mode,
                 "math": "fast (hardware transcendentals; geometry IEEE)",
-                "parallelism": f"frame-split x{world}" + (" + RCCL reduce" if world > 1 else ""),
+                "parallelism": f"frame-split x{world}" + (" + RCCL reduce overlapped with the next frame"
+                                                          if world > 1 else ""),
                 "ms_per_frame_1080p_64spp": launch_ms,
                 "rays_per_frame": rays / max(args.steps, 1),
                 "wavefront_ms_per_frame_1080p_64spp": other_ms,
@@ -226,7 +256,8 @@ def main() -> None:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    r.close()
+    for rr in renderers:
+        rr.close()
     if world > 1:
         dist.destroy_process_group()
 

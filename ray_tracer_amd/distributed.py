@@ -9,7 +9,9 @@ order of float additions).  Splitting inside a frame's sample loop would not rep
 the RNG streams, because a pixel's state advances sequentially through its samples.
 
 One process per GPU; the reduce is ``torch.distributed.reduce`` (RCCL over xGMI with the
-``nccl`` backend, gloo on CPU in the tests).
+``nccl`` backend, gloo on CPU in the tests).  start_reduce / finish_reduce split it so
+that a renderer with two accumulation images can trace the next batch while the previous
+one is being summed.
 """
 from __future__ import annotations
 
@@ -35,3 +37,23 @@ def reduce_accumulation(accum, dst: int = 0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
+
+
+def start_reduce(accum, dst: int = 0):
+    """Begin the same sum without waiting for it: returns a handle for finish_reduce, or None
+    when there is nothing to do (one rank).  With the nccl backend the sum runs on RCCL's own
+    stream after the work already queued on the current stream, so kernels launched next --
+    the following frame batch, into ANOTHER accumulation image -- overlap with it.  The
+    tensor must not be touched until finish_reduce."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def finish_reduce(handle) -> None:
+    """Order everything launched afterwards on the current stream behind the sum (nccl), or
+    block until it is done (gloo)."""
+    if handle is not None:
+        handle.wait()

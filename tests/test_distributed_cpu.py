@@ -11,7 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ray_tracer_amd.distributed import frame_partition, reduce_accumulation
+from ray_tracer_amd.distributed import (finish_reduce, frame_partition, reduce_accumulation,
+                                        start_reduce)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -27,6 +28,14 @@ def test_frame_partition_covers_every_frame_once():
             assert sorted(seen) == list(range(10, 10 + n))
     with pytest.raises(ValueError):
         frame_partition(0, 4, 2, 2)
+
+
+def test_reduce_helpers_are_no_ops_without_a_process_group():
+    t = torch.ones(4)
+    assert reduce_accumulation(t) is t
+    assert start_reduce(t) is None
+    finish_reduce(None)
+    assert torch.equal(t, torch.ones(4))
 
 
 def _free_port():
@@ -52,9 +61,15 @@ def _worker(rank, world, port, out_path):
     res = oracle.render(ubo, oracle.default_spheres(), w, h, first, count, stride, threads=2)
     accum = torch.from_numpy(res["accum"])
     rays = torch.tensor([res["rays"]], dtype=torch.int64)
-    reduce_accumulation(accum, dst=0)
+    # the split form, two images in flight as bench.py keeps them
+    twice = accum * 2.0
+    pending = [start_reduce(accum, dst=0), start_reduce(twice, dst=0)]
+    assert all(p is not None for p in pending)
+    for p in pending:
+        finish_reduce(p)
     dist.all_reduce(rays)
     if rank == 0:
+        assert torch.equal(twice, accum * 2.0)
         np.savez(out_path, accum=accum.numpy(), rays=rays.numpy())
     dist.barrier()
     dist.destroy_process_group()
