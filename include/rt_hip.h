@@ -107,6 +107,31 @@ int rt_set_spheres(rt_ctx *ctx, const void *spheres64, uint32_t count);
 int rt_set_mesh(rt_ctx *ctx, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
                 uint32_t n_triangles, const rt_material *material);
 
+/* Stands in for the sampled image the reference declares but never binds: loadTexture
+ * (main.cpp:1384-1409, no call site) would create an RGBA8 image with a LINEAR / REPEAT,
+ * single-level sampler (vulkan_texture.cpp:77-95), and the compute shader has no sampler
+ * binding.  Here ONE albedo texture can be bound to a range of primitive ids: on a hit of
+ * first_prim <= id < first_prim + n_prims the material's colour.rgb is replaced by the
+ * bilinear sample (colour.a, emission and specular stay the material's).
+ *   rgba8     width * height texels, 4 bytes each, row 0 at v = 0 (copied)
+ *   flags     RT_TEX_SRGB: bytes are sRGB-encoded and are linearised before filtering
+ *   mapping   RT_TEX_MAP_PLANAR_XZ: (u, v) = (point.x * scale_u, point.z * scale_v)
+ *             RT_TEX_MAP_OCTAHEDRAL: the unit normal folded onto a square (spheres),
+ *             (u, v) = (a * scale_u, b * scale_v) with a, b in [0, 1]
+ * One unit of u or v is one repeat of the image.  desc == NULL removes the texture. */
+#define RT_TEX_SRGB 1u
+#define RT_TEX_MAP_PLANAR_XZ 0u
+#define RT_TEX_MAP_OCTAHEDRAL 1u
+typedef struct rt_texture_desc {
+  uint32_t struct_size;          /* sizeof(rt_texture_desc) */
+  uint32_t width, height;        /* 1 .. 32768 */
+  uint32_t flags;
+  uint32_t mapping;
+  float scale_u, scale_v;
+  uint32_t first_prim, n_prims;
+} rt_texture_desc;
+int rt_set_texture(rt_ctx *ctx, const rt_texture_desc *desc, const void *rgba8);
+
 /* Replaces bind pipeline + descriptor sets + vkCmdDispatch(W/16,H/16,1) + submit,
  * main.cpp:819-868, for n_frames dispatches with ubo.frame.x = first_frame,
  * first_frame + frame_stride, ...  (main.cpp:1028 increments it by one per

@@ -61,6 +61,15 @@ uint32_t rt_default_scene(rt_sphere out3[3]);
  * material has no refraction term, so there is no dielectric class.  Returns n. */
 uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out);
 
+/* No counterpart in the reference, whose only texture is a photograph
+ * (assets/textures/brickwall.jpg, never sampled): a deterministic brick-wall pattern for
+ * tests and benchmarks.  width x height sRGB texels, 4 bytes each, written row by row.
+ * Rows of 8 courses per image height, bricks two courses long, every other course offset
+ * by half a brick, mortar joints 1/16 of a course wide; each brick's tint comes from the
+ * shader's PCG hash (ray_tracing.comp:112-119) of its course and column, and a hash of the
+ * texel adds +-4 levels of grain.  The pattern tiles seamlessly. */
+void rt_brick_texture(uint32_t width, uint32_t height, uint8_t *rgba8_out);
+
 /* Writes a binary PPM (P6) of an rgba8 image; flip_y != 0 writes the last buffer row
  * first, which is how the reference's window shows the image (negative viewport
  * height, main.cpp:934-940).  Returns 0, or -1 with errno set. */

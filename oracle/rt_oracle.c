@@ -365,6 +365,8 @@ typedef struct {
   const float *spheres; /* 16 floats per sphere */
   uint32_t n_spheres;
   const rto_mesh *mesh; /* optional triangle mesh (extension, see rt_oracle.h) */
+  const rto_texture *tex; /* optional albedo texture (extension) */
+  float tex_lut[256];     /* byte -> linear value */
   uint32_t width, height;
   const math_ops *mo;
 } frame_ctx;
@@ -458,6 +460,61 @@ static inline hit_t closest_hit(const frame_ctx *fc, v3 o, v3 d, int skip) {
   return best;
 }
 
+float rto_srgb_to_linear(uint8_t v) {
+  double c = (double)v / 255.0;
+  return (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+}
+
+/* Texture coordinates of a hit.  PLANAR_XZ: (point.x, point.z).  OCTAHEDRAL: the unit
+ * normal n folded onto the square: q = n.xz / (|n.x|+|n.y|+|n.z|); on the lower half
+ * (n.y < 0) q = (1 - |q.zx|) * sign(q.xz); (a, b) = q * 0.5 + 0.5. */
+static inline void texture_coords(const rto_texture *t, v3 point, v3 n, float *a, float *b) {
+  if (t->mapping == RTO_TEX_MAP_OCTAHEDRAL) {
+    float s = (fabsf(n.x) + fabsf(n.y)) + fabsf(n.z);
+    float qx = n.x / s, qz = n.z / s;
+    if (n.y < 0.0f) {
+      float fx = (1.0f - fabsf(qz)) * (qx >= 0.0f ? 1.0f : -1.0f);
+      float fz = (1.0f - fabsf(qx)) * (qz >= 0.0f ? 1.0f : -1.0f);
+      qx = fx; qz = fz;
+    }
+    *a = fmaf(qx, 0.5f, 0.5f);
+    *b = fmaf(qz, 0.5f, 0.5f);
+  } else {
+    *a = point.x;
+    *b = point.z;
+  }
+}
+
+/* LINEAR / REPEAT sample at (u, v), one unit = one repeat:
+ *   ur = u - floor(u);  x = ur*W - 0.5 (fused);  x0 = floor(x);  fx = x - x0;
+ *   columns x0 and x0+1 wrapped into [0, W); same for rows;
+ *   texel bytes -> floats through the 256-entry table;
+ *   lerp along x then y, each as fma(weight, right - left, left). */
+static inline v3 texture_sample(const frame_ctx *fc, float u, float v) {
+  const rto_texture *t = fc->tex;
+  const int W = (int)t->width, H = (int)t->height;
+  float ur = u - floorf(u), vr = v - floorf(v);
+  if (!(ur >= 0.0f && ur <= 1.0f)) ur = 0.0f;   /* NaN or infinite coordinate */
+  if (!(vr >= 0.0f && vr <= 1.0f)) vr = 0.0f;
+  float x = fmaf(ur, (float)W, -0.5f), y = fmaf(vr, (float)H, -0.5f);
+  float x0 = floorf(x), y0 = floorf(y);
+  float fx = x - x0, fy = y - y0;
+  int ix0 = x0 < 0.0f ? W - 1 : (int)x0, iy0 = y0 < 0.0f ? H - 1 : (int)y0;
+  if (ix0 >= W) ix0 = W - 1;
+  if (iy0 >= H) iy0 = H - 1;
+  int ix1 = ix0 + 1 == W ? 0 : ix0 + 1, iy1 = iy0 + 1 == H ? 0 : iy0 + 1;
+  const uint8_t *c00 = t->rgba8 + 4u * ((size_t)iy0 * W + ix0), *c10 = t->rgba8 + 4u * ((size_t)iy0 * W + ix1);
+  const uint8_t *c01 = t->rgba8 + 4u * ((size_t)iy1 * W + ix0), *c11 = t->rgba8 + 4u * ((size_t)iy1 * W + ix1);
+  float out[3];
+  for (int k = 0; k < 3; ++k) {
+    float a = fc->tex_lut[c00[k]], b = fc->tex_lut[c10[k]];
+    float c = fc->tex_lut[c01[k]], d = fc->tex_lut[c11[k]];
+    float top = fmaf(fx, b - a, a), bot = fmaf(fx, d - c, c);
+    out[k] = fmaf(fy, bot - top, top);
+  }
+  return V3(out[0], out[1], out[2]);
+}
+
 static inline float clamp01(float t) { return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t); }
 /* GLSL smoothstep: t = clamp((x-e0)/(e1-e0),0,1); t*t*(3-2t).  The quotient is taken as
  * (x-e0) * k with k = 1/(e1-e0) rounded to fp32 once -- one of the evaluations GLSL's
@@ -515,6 +572,12 @@ static inline v3 trace_path(const frame_ctx *fc, v3 o, v3 d, uint32_t *rng, int 
       const float *m = (uint32_t)h.index < fc->n_spheres ? fc->spheres + 16u * (uint32_t)h.index + 4
                                                          : fc->mesh->material;
       skip = (uint32_t)h.index < fc->n_spheres ? -1 : h.index;
+      v3 albedo = V3(m[0], m[1], m[2]);
+      if (fc->tex && (uint32_t)h.index - fc->tex->first_prim < fc->tex->n_prims) {
+        float ta, tb;
+        texture_coords(fc->tex, h.point, h.normal, &ta, &tb);
+        albedo = texture_sample(fc, ta * fc->tex->scale_u, tb * fc->tex->scale_v);
+      }
       o = h.point;
       v3 diffuse = v_normalize(v_add(h.normal, random_direction(fc, rng)));
       float dn2 = 2.0f * v_dot(h.normal, d);                      /* reflect(I,N) = I - 2 dot(N,I) N */
@@ -525,7 +588,7 @@ static inline v3 trace_path(const frame_ctx *fc, v3 o, v3 d, uint32_t *rng, int 
       v3 emitted = V3(m[4] * m[7], m[5] * m[7], m[6] * m[7]);
       light = V3(fmaf(emitted.x, colour.x, light.x), fmaf(emitted.y, colour.y, light.y),
                  fmaf(emitted.z, colour.z, light.z));
-      colour = v_mul(colour, v_mix(V3(m[0], m[1], m[2]), V3(m[8], m[9], m[10]), is_spec));
+      colour = v_mul(colour, v_mix(albedo, V3(m[8], m[9], m[10]), is_spec));
     } else {
       v3 env = environment(fc, d);
       light = V3(fmaf(env.x, colour.x, light.x), fmaf(env.y, colour.y, light.y),
@@ -622,7 +685,20 @@ int rto_render_mesh(const void *ubo272, const void *spheres64, uint32_t n_sphere
                     const rto_mesh *mesh, uint32_t width, uint32_t height, uint32_t first_frame,
                     uint32_t n_frames, uint32_t frame_stride, int math_mode, int accum_mode,
                     float *accum, uint8_t *rgba8, int32_t *ids, uint64_t *rays, int threads) {
+  return rto_render_scene(ubo272, spheres64, n_spheres, mesh, NULL, width, height, first_frame,
+                          n_frames, frame_stride, math_mode, accum_mode, accum, rgba8, ids, rays,
+                          threads);
+}
+
+int rto_render_scene(const void *ubo272, const void *spheres64, uint32_t n_spheres,
+                     const rto_mesh *mesh, const rto_texture *texture, uint32_t width,
+                     uint32_t height, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                     int math_mode, int accum_mode, float *accum, uint8_t *rgba8, int32_t *ids,
+                     uint64_t *rays, int threads) {
   if (!ubo272 || (!spheres64 && n_spheres) || !width || !height) return -1;
+  if (texture && (!texture->rgba8 || !texture->width || !texture->height || texture->width > 32768u ||
+                  texture->height > 32768u))
+    return -1;
   if (mesh && mesh->n_triangles == 0) mesh = NULL;
   if (mesh && (!mesh->vertices || !mesh->indices || !mesh->material)) return -1;
   if (mesh)
@@ -645,6 +721,9 @@ int rto_render_mesh(const void *ubo272, const void *spheres64, uint32_t n_sphere
   fc.sun_focus = u[64]; fc.sun_intensity = u[65]; fc.defocus = u[66]; fc.diverge = u[67];
   fc.spheres = (const float *)spheres64; fc.n_spheres = n_spheres;
   fc.mesh = mesh;
+  fc.tex = texture;
+  for (int i = 0; i < 256; ++i)
+    fc.tex_lut[i] = texture && texture->srgb ? rto_srgb_to_linear((uint8_t)i) : (float)i / 255.0f;
   fc.width = width; fc.height = height;
   fc.mo = math_mode == RTO_MATH_LIBM ? &k_libm : &k_portable;
 
@@ -665,6 +744,15 @@ int rto_render_mesh(const void *ubo272, const void *spheres64, uint32_t n_sphere
       for (int t = 0; t < threads; ++t) *rays += jobs[t].rays;
   }
   return 0;
+}
+
+void rto_texture_sample(const rto_texture *texture, float u, float v, float out_rgb[3]) {
+  static _Thread_local frame_ctx fc;
+  fc.tex = texture;
+  for (int i = 0; i < 256; ++i)
+    fc.tex_lut[i] = texture->srgb ? rto_srgb_to_linear((uint8_t)i) : (float)i / 255.0f;
+  v3 c = texture_sample(&fc, u, v);
+  out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
 }
 
 void rto_resolve_rgba8(const float *accum, uint32_t n_pixels, int accum_mode, uint8_t *rgba8) {

@@ -117,6 +117,32 @@ int rto_render_mesh(const void *ubo272, const void *spheres64, uint32_t n_sphere
                     uint32_t n_frames, uint32_t frame_stride, int math_mode, int accum_mode,
                     float *accum, uint8_t *rgba8, int32_t *ids, uint64_t *rays, int threads);
 
+/* Albedo texture (EXTENSION: the reference's shader samples no texture; its sampler state is
+ * vulkan_texture.cpp:77-95 -- LINEAR filter, REPEAT addressing, one mip level).  On a hit of
+ * primitive first_prim <= id < first_prim + n_prims the material's colour.rgb is replaced by
+ * the bilinear sample; see texture_sample() in rt_oracle.c for the arithmetic. */
+enum { RTO_TEX_MAP_PLANAR_XZ = 0, RTO_TEX_MAP_OCTAHEDRAL = 1 };
+typedef struct rto_texture {
+  const uint8_t *rgba8;       /* width*height texels, row 0 = v 0 */
+  uint32_t width, height;
+  int srgb;                   /* 1: texel bytes are sRGB-encoded, 0: linear (byte/255) */
+  int mapping;                /* RTO_TEX_MAP_* */
+  float scale_u, scale_v;
+  uint32_t first_prim, n_prims;
+} rto_texture;
+
+int rto_render_scene(const void *ubo272, const void *spheres64, uint32_t n_spheres,
+                     const rto_mesh *mesh, const rto_texture *texture, uint32_t width,
+                     uint32_t height, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                     int math_mode, int accum_mode, float *accum, uint8_t *rgba8, int32_t *ids,
+                     uint64_t *rays, int threads);
+
+/* one bilinear sample of the texture at (u, v), for unit tests of the sampling rule */
+void rto_texture_sample(const rto_texture *texture, float u, float v, float out_rgb[3]);
+
+/* byte -> linear float of the sRGB transfer function (IEC 61966-2-1), evaluated in double */
+float rto_srgb_to_linear(uint8_t v);
+
 /* accum (rgb sum, a = frame count) -> rgba8 with the image-store conversion */
 void rto_resolve_rgba8(const float *accum, uint32_t n_pixels, int accum_mode,
                        uint8_t *rgba8);

@@ -19,6 +19,9 @@ from ._capi import (  # noqa: F401
     Renderer,
     RtError,
     Stats,
+    TEX_MAP_OCTAHEDRAL,
+    TEX_MAP_PLANAR_XZ,
+    brick_texture,
     debug_eval,
     default_scene,
     default_ubo,
@@ -34,5 +37,6 @@ __all__ = [
     "LIB_PATH", "MODE_MEGAKERNEL", "MODE_MEGAKERNEL_NESTED", "MODE_WAVEFRONT",
     "FLAG_ACCUM_LINEAR", "FLAG_COUNT_TRAVERSAL", "FLAG_FORCE_BRUTE", "FLAG_FORCE_BVH", "FLAG_STRICT_MATH",
     "Camera", "Renderer", "RtError", "Stats", "debug_eval", "default_scene", "default_ubo",
+    "TEX_MAP_OCTAHEDRAL", "TEX_MAP_PLANAR_XZ", "brick_texture",
     "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "make_ubo", "matte", "terrain_mesh",
 ]

@@ -118,6 +118,9 @@ lib.rt_destroy.argtypes = [C.c_void_p]
 lib.rt_set_params.argtypes = [C.c_void_p, C.c_void_p]
 lib.rt_set_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 lib.rt_set_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+lib.rt_set_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+lib.rt_brick_texture.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+lib.rt_brick_texture.restype = None
 lib.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.rt_sync.argtypes = [C.c_void_p]
 lib.rt_clear.argtypes = [C.c_void_p]
@@ -184,6 +187,24 @@ def debug_eval(op: int, a: np.ndarray, b: Optional[np.ndarray] = None, device: i
     return out
 
 
+TEX_SRGB = 1
+TEX_MAP_PLANAR_XZ = 0
+TEX_MAP_OCTAHEDRAL = 1
+
+
+class _TextureDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("flags", C.c_uint32), ("mapping", C.c_uint32), ("scale_u", C.c_float),
+                ("scale_v", C.c_float), ("first_prim", C.c_uint32), ("n_prims", C.c_uint32)]
+
+
+def brick_texture(width: int = 256, height: int = 256) -> np.ndarray:
+    """The library's procedural brick wall, (height, width, 4) uint8 sRGB."""
+    out = np.empty((height, width, 4), dtype=np.uint8)
+    lib.rt_brick_texture(width, height, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 class Renderer:
     """One rt_ctx: an image of width x height on one GPU."""
 
@@ -229,6 +250,20 @@ class Renderer:
         m = np.ascontiguousarray(material, dtype=np.float32).reshape(12)
         _check(lib.rt_set_mesh(self._ctx, v.ctypes.data_as(C.c_void_p), v.shape[0],
                                i.ctypes.data_as(C.c_void_p), i.shape[0], m.ctypes.data_as(C.c_void_p)))
+
+    def set_texture(self, rgba8: Optional[np.ndarray], first_prim: int = 0, n_prims: int = 1,
+                    mapping: int = TEX_MAP_PLANAR_XZ, scale=(1.0, 1.0), srgb: bool = True) -> None:
+        """rgba8 (h,w,4) uint8 bound to primitives first_prim .. first_prim+n_prims-1;
+        None removes the texture."""
+        if rgba8 is None:
+            _check(lib.rt_set_texture(self._ctx, None, None))
+            return
+        t = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        if t.ndim != 3 or t.shape[2] != 4:
+            raise ValueError("texture must be (height, width, 4) uint8")
+        d = _TextureDesc(C.sizeof(_TextureDesc), t.shape[1], t.shape[0], TEX_SRGB if srgb else 0,
+                         mapping, float(scale[0]), float(scale[1]), first_prim, n_prims)
+        _check(lib.rt_set_texture(self._ctx, C.byref(d), t.ctypes.data_as(C.c_void_p)))
 
     def render(self, first_frame: int = 0, n_frames: int = 1, stride: int = 1) -> None:
         _check(lib.rt_render(self._ctx, first_frame, n_frames, stride))

@@ -69,6 +69,11 @@ struct rt_ctx {
   float mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0};  // bounds of the mesh vertices
   float mesh_material[12] = {0};
 
+  uchar4 *d_texels = nullptr;    // albedo texture (optional)
+  float *d_tex_lut = nullptr;    // byte -> linear value
+  rt::Texture *d_tex = nullptr;  // device copy of the binding
+  bool have_tex = false;
+
   rt::Lbvh bvh;                  // device LBVH + build workspace
   bool use_bvh = false;
   float bvh_cam[3] = {0.f, 0.f, 0.f};  // camera position the leaf boxes were sized for
@@ -133,6 +138,7 @@ rt::Scene scene_view(const rt_ctx *c) {
   S.n_spheres = c->n_spheres;
   S.tri = c->d_tri;
   S.n_tris = c->n_tris;
+  S.tex = c->have_tex ? c->d_tex : nullptr;
   if (c->use_bvh) {
     S.nodes = c->bvh.nodes;
     S.sorted_prim = c->bvh.sorted_prim;
@@ -241,6 +247,9 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_geom) hipFree(c->d_geom);
   if (c->d_material) hipFree(c->d_material);
   if (c->d_tri) hipFree(c->d_tri);
+  if (c->d_texels) hipFree(c->d_texels);
+  if (c->d_tex_lut) hipFree(c->d_tex_lut);
+  if (c->d_tex) hipFree(c->d_tex);
   c->bvh.release();
   c->wf.release();
   for (auto &p : c->ev_pending) c->ev_free.push_back(p);
@@ -409,6 +418,58 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
   int rc = rebuild_accel(c);
   if (rc != RT_OK) return rc;
   c->have_scene = true;
+  return RT_OK;
+}
+
+int rt_set_texture(rt_ctx *c, const rt_texture_desc *desc, const void *rgba8) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_set_texture: null context");
+  if (desc) {
+    if (desc->struct_size != sizeof(rt_texture_desc))
+      return fail(RT_ERR_INVALID, "rt_set_texture: struct_size %u, expected %zu", desc->struct_size,
+                  sizeof(rt_texture_desc));
+    if (!rgba8) return fail(RT_ERR_INVALID, "rt_set_texture: null texels");
+    if (desc->width == 0 || desc->height == 0 || desc->width > 32768u || desc->height > 32768u)
+      return fail(RT_ERR_INVALID, "rt_set_texture: bad size %ux%u", desc->width, desc->height);
+    if (desc->mapping > RT_TEX_MAP_OCTAHEDRAL)
+      return fail(RT_ERR_INVALID, "rt_set_texture: unknown mapping %u", desc->mapping);
+    if (desc->flags & ~RT_TEX_SRGB) return fail(RT_ERR_INVALID, "rt_set_texture: unknown flags 0x%x", desc->flags);
+  }
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipStreamSynchronize(c->stream));  // launches in flight may still sample the old one
+  if (c->d_texels) RT_HIP(hipFree(c->d_texels));
+  c->d_texels = nullptr;
+  c->have_tex = false;
+  if (!desc) return RT_OK;
+  const size_t n = (size_t)desc->width * desc->height;
+  RT_HIP(hipMalloc(&c->d_texels, n * sizeof(uchar4)));
+  RT_HIP(hipMemcpy(c->d_texels, rgba8, n * sizeof(uchar4), hipMemcpyHostToDevice));
+  if (!c->d_tex_lut) RT_HIP(hipMalloc(&c->d_tex_lut, 256 * sizeof(float)));
+  float lut[256];
+  for (int i = 0; i < 256; ++i) {
+    if (desc->flags & RT_TEX_SRGB) {
+      // IEC 61966-2-1 decoding, evaluated in double and rounded once
+      const double v = (double)i / 255.0;
+      lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4));
+    } else {
+      lut[i] = (float)i / 255.0f;
+    }
+  }
+  RT_HIP(hipMemcpy(c->d_tex_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+  rt::Texture t{};
+  t.texels = c->d_texels;
+  t.lut = c->d_tex_lut;
+  t.width = desc->width;
+  t.height = desc->height;
+  t.fwidth = (float)desc->width;
+  t.fheight = (float)desc->height;
+  t.scale_u = desc->scale_u;
+  t.scale_v = desc->scale_v;
+  t.first_prim = desc->first_prim;
+  t.n_prims = desc->n_prims;
+  t.mapping = desc->mapping;
+  if (!c->d_tex) RT_HIP(hipMalloc(&c->d_tex, sizeof t));
+  RT_HIP(hipMemcpy(c->d_tex, &t, sizeof t, hipMemcpyHostToDevice));
+  c->have_tex = true;
   return RT_OK;
 }
 

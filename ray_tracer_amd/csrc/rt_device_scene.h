@@ -46,6 +46,17 @@ constexpr int kBvhStackEntries = 32;  // traversal stack entries per lane (>= tr
 constexpr int kMaxLargeSpheres = 16;  // oversized spheres tested outside the tree
 constexpr int32_t kNullLeaf = (int32_t)0x80000000;  // leaf slot of a sphere kept out of the tree
 
+// Albedo texture bound to a range of primitive ids (texels == null: none).
+struct Texture {
+  const uchar4 *texels;     // width * height, row 0 = v 0
+  const float *lut;         // 256 entries: texel byte -> linear value
+  uint32_t width, height;
+  float fwidth, fheight;
+  float scale_u, scale_v;
+  uint32_t first_prim, n_prims;
+  uint32_t mapping;         // 0: planar (point.x, point.z), 1: octahedral from the normal
+};
+
 // Primitive ids: spheres 0 .. n_spheres-1, then the triangles of the mesh.
 struct Scene {
   const float4 *geom;       // per sphere: centre.xyz, radius*radius   (original order)
@@ -61,6 +72,8 @@ struct Scene {
   const float4 *large_geom;     // oversized spheres, tested before the tree
   const uint32_t *large_prim;
   uint32_t n_large;
+  const Texture *tex;       // device copy of the texture binding; null: none (kept behind a
+                            // pointer so untextured launches carry two scalar registers for it)
 };
 
 struct FrameSeq {

@@ -195,6 +195,45 @@ uint32_t rt_default_scene(rt_sphere out3[3]) {
   return 3;
 }
 
+static uint32_t pcg_hash(uint32_t v) {  // one nextRandom step from state v
+  uint32_t state = v * 747796405u + 2891336453u;
+  uint32_t r = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+  return (r >> 22) ^ r;
+}
+
+void rt_brick_texture(uint32_t width, uint32_t height, uint8_t *out) {
+  if (!out || !width || !height) return;
+  const uint32_t courses = 8, columns = 4;  // per image: 8 courses of 4 bricks
+  for (uint32_t y = 0; y < height; ++y) {
+    const uint32_t course = (uint32_t)((uint64_t)y * courses / height);
+    // position inside the course, in 1/4096 of its height
+    const uint32_t fy = (uint32_t)(((uint64_t)y * courses * 4096u / height) & 4095u);
+    for (uint32_t x = 0; x < width; ++x) {
+      // horizontal position in 1/4096 of a brick, odd courses shifted by half a brick
+      uint64_t hx = (uint64_t)x * columns * 4096u / width + ((course & 1u) ? 2048u : 0u);
+      const uint32_t column = (uint32_t)((hx >> 12) % columns);
+      const uint32_t fx = (uint32_t)(hx & 4095u);
+      // a joint is 1/16 course high; a brick is two courses long, so 1/32 of its length
+      const bool mortar = fy < 256u || fx < 128u;
+      const uint32_t grain = pcg_hash(y * 73856093u ^ x * 19349663u) & 7u;  // 0..7
+      int r, g, b;
+      if (mortar) {
+        r = g = b = 176;
+      } else {
+        const uint32_t tint = pcg_hash(course * 131u + column * 7u + 1u);
+        r = 150 + (int)(tint & 31u);
+        g = 62 + (int)((tint >> 5) & 15u);
+        b = 48 + (int)((tint >> 9) & 15u);
+      }
+      uint8_t *px = out + 4u * ((size_t)y * width + x);
+      px[0] = (uint8_t)(r + (int)grain - 4);
+      px[1] = (uint8_t)(g + (int)grain - 4);
+      px[2] = (uint8_t)(b + (int)grain - 4);
+      px[3] = 255;
+    }
+  }
+}
+
 uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out) {
   if (!out || n == 0) return 0;
   uint32_t state = seed;

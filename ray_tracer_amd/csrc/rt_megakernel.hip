@@ -22,7 +22,7 @@ namespace rt {
 
 // COUNT (only with BVH): also tallies LBVH nodes fetched and spheres tested into
 // O.rays[1] and O.rays[2].
-template <bool STRICT, bool BVH, bool COUNT = false>
+template <bool STRICT, bool BVH, bool TEX, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t px, py;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
           ++nrays;
           if (s == 0 && b == 0) id0 = h.idx;
           if (h.idx >= 0) {
-            skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
+            skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
           } else {
             light = fma3v(environment<STRICT>(P, d), colour, light);
             break;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
 }
 
 // Requires n_spp >= 1 and n_bounce >= 1 (the host routes other cases to k_mega_nested).
-template <bool STRICT, bool BVH>
+template <bool STRICT, bool BVH, bool TEX>
 __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t px, py;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -231,7 +231,7 @@ __device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search &
   }
 }
 
-template <bool STRICT>
+template <bool STRICT, bool TEX>
 __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[kBvhStack * kBlockThreads];
   uint32_t px, py;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
   if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
 }
 
-template <bool STRICT, bool BVH>
+template <bool STRICT, bool BVH, bool TEX>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
                                 const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
@@ -341,29 +341,37 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     return !(e && e[0] == '0');
   }();
   if (nested)
-    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX>), grid, block, 0, stream, P, S, F, O);
   else if (BVH && sched)
-    hipLaunchKernelGGL((k_mega_sched<STRICT>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX>), grid, block, 0, stream, P, S, F, O);
   else
-    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX>), grid, block, 0, stream, P, S, F, O);
   return hipGetLastError();
 }
 
 hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const FrameSeq &F,
                                       const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
-  hipLaunchKernelGGL((k_mega_nested<false, true, true>), grid, dim3(256), 0, stream, P, S, F, O);
+  if (S.tex)
+    hipLaunchKernelGGL((k_mega_nested<false, true, true, true>), grid, dim3(256), 0, stream, P, S, F, O);
+  else
+    hipLaunchKernelGGL((k_mega_nested<false, true, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
   return hipGetLastError();
 }
 
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
                              const FrameSeq &F, const Outputs &O, hipStream_t stream) {
-  if (strict) {
-    return bvh ? launch_mega_t<true, true>(nested, P, S, F, O, stream)
-               : launch_mega_t<true, false>(nested, P, S, F, O, stream);
+  const int variant = (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
+  switch (variant) {
+    case 0: return launch_mega_t<false, false, false>(nested, P, S, F, O, stream);
+    case 1: return launch_mega_t<false, false, true>(nested, P, S, F, O, stream);
+    case 2: return launch_mega_t<false, true, false>(nested, P, S, F, O, stream);
+    case 3: return launch_mega_t<false, true, true>(nested, P, S, F, O, stream);
+    case 4: return launch_mega_t<true, false, false>(nested, P, S, F, O, stream);
+    case 5: return launch_mega_t<true, false, true>(nested, P, S, F, O, stream);
+    case 6: return launch_mega_t<true, true, false>(nested, P, S, F, O, stream);
+    default: return launch_mega_t<true, true, true>(nested, P, S, F, O, stream);
   }
-  return bvh ? launch_mega_t<false, true>(nested, P, S, F, O, stream)
-             : launch_mega_t<false, false>(nested, P, S, F, O, stream);
 }
 
 }  // namespace rt

@@ -201,6 +201,56 @@ __device__ __forceinline__ float normal_draw(uint32_t &rng) {
   return M::sqrt(M::neg2log(u2)) * M::box_cos(u1);
 }
 
+// ---- albedo texture (extension; sampler state of vulkan_texture.cpp:77-95: LINEAR filter,
+// REPEAT addressing, one level) -----------------------------------------------------------
+// Coordinates of a hit.  Planar: (point.x, point.z).  Octahedral: the unit normal folded
+// onto the square, q = n.xz / (|n.x|+|n.y|+|n.z|), lower half (n.y < 0) mirrored outwards,
+// (a, b) = q/2 + 1/2.
+__device__ __forceinline__ void texture_coords(const Texture &T, f3 p, f3 n, float &a, float &b) {
+  if (T.mapping == 1u) {
+    const float s = (__builtin_fabsf(n.x) + __builtin_fabsf(n.y)) + __builtin_fabsf(n.z);
+    float qx = ieee_div(n.x, s), qz = ieee_div(n.z, s);
+    if (n.y < 0.0f) {
+      const float fx = (1.0f - __builtin_fabsf(qz)) * (qx >= 0.0f ? 1.0f : -1.0f);
+      const float fz = (1.0f - __builtin_fabsf(qx)) * (qz >= 0.0f ? 1.0f : -1.0f);
+      qx = fx;
+      qz = fz;
+    }
+    a = __builtin_fmaf(qx, 0.5f, 0.5f);
+    b = __builtin_fmaf(qz, 0.5f, 0.5f);
+  } else {
+    a = p.x;
+    b = p.z;
+  }
+}
+
+// Bilinear sample, one unit of (u, v) = one repeat: the fractional part of the coordinate
+// picks the position, texel centres at half-integers, the two columns and rows wrap,
+// bytes become floats through the table, lerps are fma(weight, right - left, left).
+__device__ __forceinline__ f3 texture_sample(const Texture &T, float u, float v) {
+  const int W = (int)T.width, H = (int)T.height;
+  float ur = u - __builtin_floorf(u), vr = v - __builtin_floorf(v);
+  if (!(ur >= 0.0f && ur <= 1.0f)) ur = 0.0f;
+  if (!(vr >= 0.0f && vr <= 1.0f)) vr = 0.0f;
+  const float x = __builtin_fmaf(ur, T.fwidth, -0.5f), y = __builtin_fmaf(vr, T.fheight, -0.5f);
+  const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+  const float fx = x - x0, fy = y - y0;
+  int ix0 = x0 < 0.0f ? W - 1 : (int)x0, iy0 = y0 < 0.0f ? H - 1 : (int)y0;
+  if (ix0 >= W) ix0 = W - 1;
+  if (iy0 >= H) iy0 = H - 1;
+  const int ix1 = ix0 + 1 == W ? 0 : ix0 + 1, iy1 = iy0 + 1 == H ? 0 : iy0 + 1;
+  const uchar4 c00 = T.texels[(size_t)iy0 * W + ix0], c10 = T.texels[(size_t)iy0 * W + ix1];
+  const uchar4 c01 = T.texels[(size_t)iy1 * W + ix0], c11 = T.texels[(size_t)iy1 * W + ix1];
+  const float *L = T.lut;
+  auto lerp2 = [&](unsigned char a, unsigned char b, unsigned char c, unsigned char d) {
+    const float fa = L[a], fb = L[b], fc = L[c], fd = L[d];
+    const float top = __builtin_fmaf(fx, fb - fa, fa), bot = __builtin_fmaf(fx, fd - fc, fc);
+    return __builtin_fmaf(fy, bot - top, top);
+  };
+  return mk3(lerp2(c00.x, c10.x, c01.x, c11.x), lerp2(c00.y, c10.y, c01.y, c11.y),
+             lerp2(c00.z, c10.z, c01.z, c11.z));
+}
+
 // Hit point, surface normal and material of primitive idx hit at distance dst.
 // Sphere: hitPoint = origin + dir*dst, normal = normalize(hitPoint - centre) (:164-165).
 // Triangle: normal = normalize(e1 x e2) turned against the ray.  Returns the id the next
@@ -230,12 +280,13 @@ __device__ __forceinline__ int hit_surface(const Scene &S, int idx, float dst, f
   return skip;
 }
 
-// On a hit at point p with normal n: new origin and direction, emitted light added,
-// throughput updated (:199-213).
+// On a hit at point p with normal n: new origin and direction, emitted light added
+// (:199-211).  Returns isSpecularBounce (0 or 1); the throughput update (:212-213) is
+// scatter_throughput, applied by the caller once it knows the surface colour.
 template <bool STRICT>
-__device__ __forceinline__ void scatter(f3 p, f3 n, float4 m_colour, float4 m_emission,
-                                        float4 m_specular, uint32_t &rng, f3 &o, f3 &d,
-                                        f3 &light, f3 &colour) {
+__device__ __forceinline__ float scatter(f3 p, f3 n, float smoothness, float4 m_emission,
+                                         float specular_probability, uint32_t &rng, f3 &o, f3 &d,
+                                         f3 &light, f3 colour) {
   using M = Math<STRICT>;
   o = p;                                     // (:201)
   float x = normal_draw<STRICT>(rng);        // randomDirection (:127-132)
@@ -246,13 +297,16 @@ __device__ __forceinline__ void scatter(f3 p, f3 n, float4 m_colour, float4 m_em
   float dn2 = 2.0f * dot(n, d);              // reflect(I, N) = I - 2 dot(N, I) N (:203)
   f3 spec = mk3(__builtin_fmaf(-dn2, n.x, d.x), __builtin_fmaf(-dn2, n.y, d.y),
                 __builtin_fmaf(-dn2, n.z, d.z));
-  float is_spec = (m_specular.w >= pcg_float(rng)) ? 1.0f : 0.0f;  // (:204-205)
-  d = mix3(diffuse, spec, m_colour.w * is_spec);                   // (:206-207)
+  float is_spec = (specular_probability >= pcg_float(rng)) ? 1.0f : 0.0f;  // (:204-205)
+  d = mix3(diffuse, spec, smoothness * is_spec);                          // (:206-207)
   f3 emitted = mk3(m_emission.x * m_emission.w, m_emission.y * m_emission.w,
                    m_emission.z * m_emission.w);                  // (:209-210)
   light = fma3v(emitted, colour, light);                           // (:211)
-  colour = colour * mix3(mk3(m_colour.x, m_colour.y, m_colour.z),
-                         mk3(m_specular.x, m_specular.y, m_specular.z), is_spec);  // (:212-213)
+  return is_spec;
+}
+
+__device__ __forceinline__ f3 scatter_throughput(f3 colour, f3 albedo, float4 m_specular, float is_spec) {
+  return colour * mix3(albedo, mk3(m_specular.x, m_specular.y, m_specular.z), is_spec);  // (:212-213)
 }
 
 // ---- per-frame pixel epilogue (ray_tracing.comp:98-109) ------------------------------

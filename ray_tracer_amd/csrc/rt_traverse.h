@@ -137,14 +137,32 @@ template <bool BVH>
 constexpr int bvh_stack_words() { return BVH ? kBvhStack * kBlockThreads : 1; }
 
 // One hit bounce: surface at the hit, then the shader's scatter.  Returns the primitive the
-// next segment must skip.
-template <bool STRICT>
+// next segment must skip.  TEX kernels (launched only while a texture is bound) replace the
+// material colour by the texture sample; its coordinates are taken at the hit and the
+// texels are fetched last, when little else is live.  Kernels without TEX carry none of it.
+template <bool STRICT, bool TEX>
 __device__ __forceinline__ int shade_hit(const Scene &S, Hit h, uint32_t &rng, f3 &o, f3 &d,
                                          f3 &light, f3 &colour) {
   f3 p, n;
   float4 mc, me, ms;
   const int skip = hit_surface(S, h.idx, h.dst, o, d, p, n, mc, me, ms);
-  scatter<STRICT>(p, n, mc, me, ms, rng, o, d, light, colour);
+  bool textured = false;
+  float tu = 0.0f, tv = 0.0f;
+  if constexpr (TEX) {
+    textured = (uint32_t)h.idx - S.tex->first_prim < S.tex->n_prims;
+    if (textured) {
+      texture_coords(*S.tex, p, n, tu, tv);
+      tu *= S.tex->scale_u;
+      tv *= S.tex->scale_v;
+    }
+  }
+  const float is_spec = scatter<STRICT>(p, n, mc.w, me, ms.w, rng, o, d, light, colour);
+  f3 albedo = mk3(mc.x, mc.y, mc.z);
+  if constexpr (TEX) {
+    // a specular bounce gives the colour weight 0 and every texel is finite: skip the fetch
+    if (textured && is_spec == 0.0f) albedo = texture_sample(*S.tex, tu, tv);
+  }
+  colour = scatter_throughput(colour, albedo, ms, is_spec);
   return skip;
 }
 

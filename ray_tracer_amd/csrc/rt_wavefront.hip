@@ -158,7 +158,7 @@ __device__ __forceinline__ bool path_end(const Params &P, const WfView &V, const
   return true;
 }
 
-template <bool STRICT>
+template <bool STRICT, bool TEX>
 __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, uint32_t slot,
                                                   uint32_t frame, Outputs O) {
   const uint32_t *cnt = V.counts + 4u * (slot & 3u);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, u
         Hit h;
         h.dst = hrec.x;
         h.idx = idx;
-        const int skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
+        const int skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
         ++b;
         if (b >= (uint32_t)P.n_bounce) {
           path_end<STRICT>(P, V, O, frame, px, rng, s, light);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels)
 
 // Finishes every pixel of the drain queue in registers: the loop of the regenerating
 // megakernel, resumed from the stored path state, for this one frame.
-template <bool STRICT, bool BVH>
+template <bool STRICT, bool BVH, bool TEX>
 __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, uint32_t frame,
                                                   Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -346,7 +346,7 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
   return 0;
 }
 
-template <bool STRICT, bool BVH>
+template <bool STRICT, bool BVH, bool TEX>
 static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const Params &P,
                     const Scene &S, uint32_t frame, const Outputs &O, hipStream_t stream,
                     uint32_t *launches, std::string *err) {
@@ -366,14 +366,14 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
     const uint32_t slot = (uint32_t)(it & 3u);
     if (bound <= drain_threshold) {
       hipLaunchKernelGGL(k_wf_compact, dim3(window_blocks), dim3(256), 0, stream, V, n);
-      hipLaunchKernelGGL((k_wf_drain<STRICT, BVH>), dim3((bound + 255u) / 256u), dim3(256), 0, stream,
+      hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, TEX>), dim3((bound + 255u) / 256u), dim3(256), 0, stream,
                          P, S, V, frame, O);
       *launches += 2;
       break;
     }
     hipLaunchKernelGGL((k_wf_extend<BVH>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                        O.ids);
-    hipLaunchKernelGGL((k_wf_shade<STRICT>), dim3((bound + kWfChunk - 1u) / kWfChunk + 1u), dim3(256),
+    hipLaunchKernelGGL((k_wf_shade<STRICT, TEX>), dim3((bound + kWfChunk - 1u) / kWfChunk + 1u), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
     *launches += 2;
     if ((it + 1) % kCheckEvery == 0) {
@@ -410,12 +410,22 @@ int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &
   *launches = 0;
   for (uint32_t fi = 0; fi < F.count; ++fi) {
     const uint32_t frame = F.first + fi * F.stride;
-    if (strict)
-      rc = bvh ? wf_frame<true, true>(impl, drain_threshold, P, S, frame, O, stream, launches, err)
-               : wf_frame<true, false>(impl, drain_threshold, P, S, frame, O, stream, launches, err);
-    else
-      rc = bvh ? wf_frame<false, true>(impl, drain_threshold, P, S, frame, O, stream, launches, err)
-               : wf_frame<false, false>(impl, drain_threshold, P, S, frame, O, stream, launches, err);
+    const int variant = (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
+#define RT_WF_CASE(n, a, b, c)                                                             \
+  case n:                                                                                  \
+    rc = wf_frame<a, b, c>(impl, drain_threshold, P, S, frame, O, stream, launches, err);  \
+    break;
+    switch (variant) {
+      RT_WF_CASE(0, false, false, false)
+      RT_WF_CASE(1, false, false, true)
+      RT_WF_CASE(2, false, true, false)
+      RT_WF_CASE(3, false, true, true)
+      RT_WF_CASE(4, true, false, false)
+      RT_WF_CASE(5, true, false, true)
+      RT_WF_CASE(6, true, true, false)
+      RT_WF_CASE(7, true, true, true)
+    }
+#undef RT_WF_CASE
     if (rc) return rc;
   }
   return 0;

@@ -32,9 +32,22 @@ class Mesh(C.Structure):
                 ("n_triangles", C.c_uint32), ("material", C.c_void_p)]
 
 
-L.rto_render_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Mesh), C.c_uint32,
-                              C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
-                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("srgb", C.c_int), ("mapping", C.c_int), ("scale_u", C.c_float),
+                ("scale_v", C.c_float), ("first_prim", C.c_uint32), ("n_prims", C.c_uint32)]
+
+
+TEX_MAP_PLANAR_XZ, TEX_MAP_OCTAHEDRAL = 0, 1
+
+L.rto_render_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Mesh),
+                               C.POINTER(Texture), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                               C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_int]
+L.rto_texture_sample.argtypes = [C.POINTER(Texture), C.c_float, C.c_float, C.c_void_p]
+L.rto_texture_sample.restype = None
+L.rto_srgb_to_linear.argtypes = [C.c_uint8]
+L.rto_srgb_to_linear.restype = C.c_float
 
 
 class Camera(C.Structure):
@@ -121,9 +134,10 @@ def pm(name, x, y=None):
 
 def render(ubo, spheres, width, height, first_frame=0, n_frames=1, stride=1,
            math_mode=MATH_PORTABLE, accum_mode=ACCUM_GAMMA, threads=8, accum=None, rgba8=None,
-           mesh=None):
+           mesh=None, texture=None):
     """Returns dict(accum, rgba8, ids, rays).  accum/rgba8 may be passed in to continue.
-    mesh = (vertices (n,3) float32, indices (m,3) uint32, material (12,) float32) or None."""
+    mesh = (vertices (n,3) float32, indices (m,3) uint32, material (12,) float32) or None.
+    texture = dict(rgba8=(h,w,4) uint8, first_prim, n_prims, mapping, scale=(su,sv), srgb) or None."""
     ubo = np.ascontiguousarray(ubo, dtype=np.float32)
     spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 16)
     if accum is None:
@@ -139,13 +153,34 @@ def render(ubo, spheres, width, height, first_frame=0, n_frames=1, stride=1,
         m = np.ascontiguousarray(mesh[2], dtype=np.float32).reshape(12)
         mstruct = Mesh(v.ctypes.data, v.shape[0], i.ctypes.data, i.shape[0], m.ctypes.data)
         mptr = C.byref(mstruct)
-    rc = L.rto_render_mesh(ubo.ctypes.data_as(C.c_void_p), spheres.ctypes.data_as(C.c_void_p),
-                           spheres.shape[0], mptr, width, height, first_frame, n_frames, stride,
-                           math_mode, accum_mode, accum.ctypes.data_as(C.c_void_p),
-                           rgba8.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
-                           C.byref(rays), threads)
+    tptr = None
+    if texture is not None:
+        tex = np.ascontiguousarray(texture["rgba8"], dtype=np.uint8)
+        scale = texture.get("scale", (1.0, 1.0))
+        tstruct = Texture(tex.ctypes.data, tex.shape[1], tex.shape[0], int(texture.get("srgb", True)),
+                          int(texture.get("mapping", TEX_MAP_PLANAR_XZ)), float(scale[0]),
+                          float(scale[1]), int(texture.get("first_prim", 0)),
+                          int(texture.get("n_prims", 1)))
+        tptr = C.byref(tstruct)
+    rc = L.rto_render_scene(ubo.ctypes.data_as(C.c_void_p), spheres.ctypes.data_as(C.c_void_p),
+                            spheres.shape[0], mptr, tptr, width, height, first_frame, n_frames,
+                            stride, math_mode, accum_mode, accum.ctypes.data_as(C.c_void_p),
+                            rgba8.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                            C.byref(rays), threads)
     assert rc == 0
     return dict(accum=accum, rgba8=rgba8, ids=ids, rays=int(rays.value))
+
+
+def texture_sample(rgba8, u, v, srgb=False):
+    tex = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    t = Texture(tex.ctypes.data, tex.shape[1], tex.shape[0], int(srgb), 0, 1.0, 1.0, 0, 1)
+    out = np.zeros(3, dtype=np.float32)
+    L.rto_texture_sample(C.byref(t), u, v, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def srgb_to_linear(v):
+    return float(L.rto_srgb_to_linear(int(v)))
 
 
 def resolve_rgba8(accum, accum_mode=ACCUM_GAMMA):

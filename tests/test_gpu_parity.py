@@ -475,3 +475,98 @@ def test_large_mesh_kernels_agree():
     for other in (b, c):
         assert np.array_equal(a["ids"], other["ids"]) and a["rays"] == other["rays"]
         assert np.array_equal(_bits(a["accum"]), _bits(other["accum"]))
+
+
+# ---------------------------------------------------------------- albedo texture (extension)
+def gpu_render_textured(ubo, spheres, mesh, tex, w, h, mode, flags, first=0, n=1, stride=1):
+    with rt.Renderer(w, h, mode=mode, flags=flags) as r:
+        r.set_params(ubo)
+        r.set_spheres(spheres)
+        if mesh is not None:
+            r.set_mesh(*mesh)
+        r.set_texture(tex["rgba8"], tex["first_prim"], tex["n_prims"], tex.get("mapping", 0),
+                      tex.get("scale", (1.0, 1.0)), tex.get("srgb", True))
+        r.render(first, n, stride)
+        r.sync()
+        st = r.stats()
+        return dict(accum=r.read_accum(), rgba8=r.read_rgba8(), ids=r.read_primary_ids(),
+                    rays=int(st.rays), stats=st)
+
+
+def _assert_exact(got, want):
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+    assert np.array_equal(got["rgba8"], want["rgba8"])
+
+
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT])
+@pytest.mark.parametrize("binding", ["ground-planar", "sphere-octahedral"])
+def test_textured_default_scene_bit_exact(oracle, mode, binding):
+    w, h = 160, 96
+    ubo = rt.make_ubo(w, h, 3, 8)
+    sph = rt.default_scene()
+    bricks = rt.brick_texture(128, 64)
+    if binding == "ground-planar":
+        tex = dict(rgba8=bricks, first_prim=2, n_prims=1, mapping=rt.TEX_MAP_PLANAR_XZ, scale=(0.5, 0.25))
+    else:
+        tex = dict(rgba8=bricks, first_prim=0, n_prims=2, mapping=rt.TEX_MAP_OCTAHEDRAL, scale=(3.0, 3.0))
+    want = oracle.render(ubo, sph, w, h, 0, 2, 1, texture=tex)
+    plain = oracle.render(ubo, sph, w, h, 0, 2, 1)
+    assert not np.array_equal(want["accum"], plain["accum"])
+    got = gpu_render_textured(ubo, sph, None, tex, w, h, mode, rt.FLAG_STRICT_MATH, 0, 2, 1)
+    _assert_exact(got, want)
+
+
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT])
+def test_textured_lbvh_scene_bit_exact(oracle, mode):
+    """300 spheres through the LBVH, bricks on the ground sphere (primitive 0)."""
+    w, h = 128, 80
+    ubo = rt.make_ubo(w, h, 2, 6)
+    sph = rt.grid_spheres_scene(300)
+    tex = dict(rgba8=rt.brick_texture(64, 64), first_prim=0, n_prims=1, scale=(0.2, 0.2))
+    want = oracle.render(ubo, sph, w, h, texture=tex)
+    got = gpu_render_textured(ubo, sph, None, tex, w, h, mode, rt.FLAG_STRICT_MATH)
+    assert got["stats"].bvh_nodes == 299
+    _assert_exact(got, want)
+
+
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT])
+def test_textured_mesh_bit_exact(oracle, mode):
+    """The texture bound to the triangles of a terrain (ids n_spheres ...), planar mapping."""
+    w, h = 128, 72
+    ubo = rt.make_ubo(w, h, 2, 8)
+    sph = rt.default_scene()
+    sph[2, :4] = (0, -1000, -5, 1)
+    v, i = rt.terrain_mesh(18, phase=0.3, size=30.0, depth=-14.0)
+    mat = rt.matte(0.7, 0.6, 0.4, smoothness=0.6, specular_probability=0.3)
+    tex = dict(rgba8=rt.brick_texture(96, 96), first_prim=3, n_prims=i.shape[0], scale=(0.3, 0.3), srgb=False)
+    want = oracle.render(ubo, sph, w, h, mesh=(v, i, mat), texture=tex)
+    got = gpu_render_textured(ubo, sph, (v, i, mat), tex, w, h, mode, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+    _assert_exact(got, want)
+
+
+def test_textured_fast_mode_and_removal(oracle):
+    w, h = 192, 108
+    ubo = rt.make_ubo(w, h, 8, 8)
+    sph = rt.default_scene()
+    tex = dict(rgba8=rt.brick_texture(256, 256), first_prim=2, n_prims=1, scale=(0.5, 0.5))
+    want = oracle.render(ubo, sph, w, h, texture=tex)
+    with rt.Renderer(w, h) as r:
+        r.set_params(ubo)
+        r.set_spheres(sph)
+        r.set_texture(tex["rgba8"], 2, 1, rt.TEX_MAP_PLANAR_XZ, (0.5, 0.5))
+        r.render(0, 1, 1)
+        got = r.read_accum()
+        assert np.array_equal(r.read_primary_ids(), want["ids"]) or \
+            (r.read_primary_ids() != want["ids"]).mean() < 1e-4
+        # fast math: hardware transcendentals in the sampling code only
+        assert psnr(got[..., :3], want["accum"][..., :3]) >= 40.0
+        r.clear()
+        r.set_texture(None)
+        r.render(0, 1, 1)
+        plain = oracle.render(ubo, sph, w, h)
+        assert psnr(r.read_accum()[..., :3], plain["accum"][..., :3]) >= 40.0
+        assert psnr(r.read_accum()[..., :3], want["accum"][..., :3]) < 40.0
+        with pytest.raises(rt.RtError):
+            r.set_texture(np.zeros((0, 4, 4), np.uint8))

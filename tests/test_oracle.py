@@ -252,3 +252,84 @@ def test_triangle_floor_does_not_hit_itself(oracle):
     assert hits > 0
     assert r["rays"] <= 2 * w * h * spp
     assert r["rays"] > w * h * spp
+
+
+# ---------------------------------------------------------------- albedo texture (extension)
+def test_srgb_table_known_values(oracle):
+    assert oracle.srgb_to_linear(0) == 0.0
+    assert oracle.srgb_to_linear(255) == 1.0
+    assert oracle.srgb_to_linear(10) == np.float32(10 / 255 / 12.92)            # linear toe
+    assert abs(oracle.srgb_to_linear(128) - 0.2158605) < 1e-7
+    assert abs(oracle.srgb_to_linear(188) - 0.5028865) < 1e-7
+    table = [oracle.srgb_to_linear(i) for i in range(256)]
+    assert all(b > a for a, b in zip(table, table[1:]))
+
+
+def test_texture_sampling_rule(oracle):
+    """LINEAR filter, REPEAT addressing, texel centres at half-integers."""
+    tex = np.zeros((2, 4, 4), np.uint8)
+    tex[0, :, 0] = (0, 51, 102, 255)      # row 0, red channel
+    tex[1, :, 0] = (255, 255, 255, 255)
+    tex[..., 1] = 51
+    tex[..., 3] = 255
+    f = lambda b: np.float32(b) / np.float32(255)
+    # texel centres return the texel
+    for x, b in enumerate((0, 51, 102, 255)):
+        got = oracle.texture_sample(tex, (x + 0.5) / 4, 0.25)
+        assert got[0] == f(b) and got[1] == f(51) and got[2] == 0.0
+    # half way between two columns: the mean
+    assert oracle.texture_sample(tex, 1.0 / 4, 0.25)[0] == np.float32((f(0) + f(51)) / 2)
+    # u = 0 lies between the last and the first column (REPEAT), also one period away
+    edge = oracle.texture_sample(tex, 0.0, 0.25)[0]
+    assert edge == np.float32((f(255) + f(0)) / 2)
+    assert oracle.texture_sample(tex, 3.0, 0.25)[0] == edge
+    assert oracle.texture_sample(tex, -2.0, 0.25)[0] == edge
+    # v = 0.5 is half way between the rows; v wraps too
+    assert oracle.texture_sample(tex, 0.125, 0.5)[0] == np.float32((f(0) + f(255)) / 2)
+    assert oracle.texture_sample(tex, 0.125, 1.25)[0] == oracle.texture_sample(tex, 0.125, 0.25)[0]
+    # non-finite coordinates sample the origin instead of faulting
+    assert np.isfinite(oracle.texture_sample(tex, float("nan"), float("inf"))).all()
+
+
+def test_uniform_texture_equals_material_colour(oracle):
+    """A one-colour linear texture must reproduce the untextured image bit for bit."""
+    w, h = 64, 48
+    cam = oracle.camera_create(90.0, w / h, 0.01, 10000.0)
+    cam.viewport_width, cam.viewport_height = float(w), float(h)
+    ubo = oracle.default_ubo(cam)
+    ubo[40], ubo[41] = 2, 6
+    sph = oracle.default_spheres().copy()
+    sph[2, 4:7] = (102 / 255, 51 / 255, 204 / 255)
+    plain = oracle.render(ubo, sph, w, h)
+    tex = np.zeros((3, 5, 4), np.uint8)
+    tex[...] = (102, 51, 204, 255)
+    sph2 = sph.copy()
+    sph2[2, 4:7] = (0.9, 0.9, 0.9)        # must be overridden by the texture
+    for mapping in (oracle.TEX_MAP_PLANAR_XZ, oracle.TEX_MAP_OCTAHEDRAL):
+        got = oracle.render(ubo, sph2, w, h, texture=dict(rgba8=tex, first_prim=2, n_prims=1,
+                                                          mapping=mapping, scale=(0.37, 1.9), srgb=False))
+        assert np.array_equal(got["accum"], plain["accum"]) and got["rays"] == plain["rays"]
+    # bound to another primitive range it changes nothing for the ground
+    other = oracle.render(ubo, sph2, w, h, texture=dict(rgba8=tex, first_prim=7, n_prims=3, srgb=False))
+    assert not np.array_equal(other["accum"], plain["accum"])
+
+
+def test_brick_texture_changes_the_ground(oracle):
+    import ray_tracer_amd as rt
+    w, h = 96, 64
+    cam = oracle.camera_create(90.0, w / h, 0.01, 10000.0)
+    cam.viewport_width, cam.viewport_height = float(w), float(h)
+    ubo = oracle.default_ubo(cam)
+    ubo[40], ubo[41] = 4, 6
+    sph = oracle.default_spheres()
+    tex = rt.brick_texture(64, 64)
+    assert tex.shape == (64, 64, 4) and (tex[..., 3] == 255).all()
+    assert np.array_equal(tex, rt.brick_texture(64, 64))
+    plain = oracle.render(ubo, sph, w, h)
+    bricks = oracle.render(ubo, sph, w, h, texture=dict(rgba8=tex, first_prim=2, n_prims=1, scale=(0.5, 0.5)))
+    assert np.array_equal(bricks["ids"], plain["ids"])
+    ground = plain["ids"] == 2
+    diff = np.abs(bricks["accum"][..., :3] - plain["accum"][..., :3]).sum(-1)
+    assert (diff[ground] > 0).mean() > 0.9          # the ground is recoloured
+    sky = plain["ids"] == -1
+    assert (diff[sky] == 0).mean() > 0.98          # sky pixels never see it (horizon jitter aside)
