@@ -85,6 +85,10 @@ struct rt_ctx {
   uchar4 *d_rgba8 = nullptr;
   int32_t *d_ids = nullptr;
   unsigned long long *d_rays = nullptr;
+  // tile scheduling of the megakernels: cost measured by the last launch, order for the next
+  uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
+  uint32_t tiles_x = 0, n_tiles = 0;
+  bool order_valid = false, use_tile_order = true;
 
   // HIP event pairs around each rt_render; resolved lazily so rendering never waits
   struct EventPair {
@@ -227,6 +231,15 @@ int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
   if ((e = hipMalloc(&c->d_ids, c->n_pixels * sizeof(int32_t))) != hipSuccess)
     return bail(e, "hipMalloc(ids)");
   if ((e = hipMalloc(&c->d_rays, 256)) != hipSuccess) return bail(e, "hipMalloc(rays)");
+  c->tiles_x = (cfg->width + 15u) / 16u;
+  c->n_tiles = c->tiles_x * ((cfg->height + 15u) / 16u);
+  if ((e = hipMalloc(&c->d_tile_cost, c->n_tiles * sizeof(uint32_t))) != hipSuccess)
+    return bail(e, "hipMalloc(tile cost)");
+  if ((e = hipMalloc(&c->d_tile_order, c->n_tiles * sizeof(uint32_t))) != hipSuccess)
+    return bail(e, "hipMalloc(tile order)");
+  if ((e = hipMemsetAsync(c->d_tile_cost, 0, c->n_tiles * sizeof(uint32_t), c->stream)) != hipSuccess)
+    return bail(e, "hipMemsetAsync(tile cost)");
+  if (const char *env = std::getenv("RT_TILE_ORDER")) c->use_tile_order = env[0] != '0';
   int rc = rt_clear(c);
   if (rc != RT_OK) {
     rt_destroy(c);
@@ -244,6 +257,8 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_rgba8) hipFree(c->d_rgba8);
   if (c->d_ids) hipFree(c->d_ids);
   if (c->d_rays) hipFree(c->d_rays);
+  if (c->d_tile_cost) hipFree(c->d_tile_cost);
+  if (c->d_tile_order) hipFree(c->d_tile_order);
   if (c->d_geom) hipFree(c->d_geom);
   if (c->d_material) hipFree(c->d_material);
   if (c->d_tri) hipFree(c->d_tri);
@@ -490,6 +505,12 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
   O.ids = c->d_ids;
   O.rays = c->d_rays;
   O.linear_accum = (c->flags & RT_FLAG_ACCUM_LINEAR) ? 1u : 0u;
+  O.tiles_x = c->tiles_x;
+  O.n_tiles = c->n_tiles;
+  if (c->use_tile_order) {
+    O.tile_cost = c->d_tile_cost;
+    O.tile_order = c->order_valid ? c->d_tile_order : nullptr;
+  }
   const rt::Scene S = scene_view(c);
   const bool strict = (c->flags & RT_FLAG_STRICT_MATH) != 0;
   const bool degenerate = c->P.n_spp < 1 || c->P.n_bounce < 1;
@@ -497,6 +518,7 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
   hipError_t he = hipEventRecord(ev.begin, c->stream);
   uint32_t launches = 0;
   int rc = RT_OK;
+  bool ordered = false;
   std::string err;
   if (he == hipSuccess) {
     if (c->mode == RT_MODE_WAVEFRONT && !degenerate) {
@@ -508,9 +530,15 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
       const bool nested = degenerate || c->mode == RT_MODE_MEGAKERNEL_NESTED;
       he = rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream);
       launches = 1;
+      ordered = !nested && c->use_tile_order;
     }
   }
   if (he == hipSuccess && rc == RT_OK) he = hipEventRecord(ev.end, c->stream);
+  if (he == hipSuccess && rc == RT_OK && ordered) {
+    // what this launch measured becomes the next launch's order (outside the timed pair)
+    he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, c->stream);
+    if (he == hipSuccess) c->order_valid = true;
+  }
   if (he != hipSuccess || rc != RT_OK) {
     c->ev_free.push_back(ev);
     if (rc != RT_OK) return fail(rc, "rt_render: wavefront: %s", err.c_str());

@@ -86,6 +86,14 @@ struct Outputs {
   int32_t *ids;             // first-segment hit of sample 0 (last frame wins)
   unsigned long long *rays; // += closest-hit searches
   uint32_t linear_accum;    // 1: accumulate the linear mean, 0: the gamma-encoded colour
+  // Launch order of the 16x16-pixel tiles (k_mega_regen, k_mega_sched): block b renders tile
+  // tile_order[b].  The order is heaviest-first by the cost the previous launch of this
+  // context measured (tile_cost: the most path segments any pixel of the tile traced), so
+  // the few tiles whose pixels run long serial chains of samples start first instead of
+  // last.  Both null: row-major order, nothing recorded.
+  const uint32_t *tile_order;
+  uint32_t *tile_cost;
+  uint32_t tiles_x, n_tiles;
 };
 
 }  // namespace rt

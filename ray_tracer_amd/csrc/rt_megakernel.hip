@@ -78,12 +78,39 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
   }
 }
 
+// Tile of this block under the launch-order table, and the issue priority that goes with its
+// rank: the first blocks of an ordered launch are the tiles with the longest per-pixel
+// chains of samples; they are on the critical path of the launch, so their waves issue
+// ahead of the waves they share a SIMD with.
+#ifndef RT_PRIO_TOP
+#define RT_PRIO_TOP 64   // ranks below n_tiles / RT_PRIO_TOP run at priority 3
+#endif
+__device__ __forceinline__ uint32_t ordered_tile(const Outputs &O) {
+  if (!O.tile_order) return blockIdx.x;
+  const uint32_t rank = blockIdx.x;
+  if (rank * RT_PRIO_TOP < O.n_tiles) __builtin_amdgcn_s_setprio(3);
+  else if (rank * (RT_PRIO_TOP / 4) < O.n_tiles) __builtin_amdgcn_s_setprio(2);
+  else if (rank * (RT_PRIO_TOP / 16) < O.n_tiles) __builtin_amdgcn_s_setprio(1);
+  return O.tile_order[rank];
+}
+
+// per-wave epilogue: path segments into the ray counter, slowest pixel into the tile's cost
+__device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint32_t nrays) {
+  const uint32_t wsum = wave_sum_u32(nrays);
+  const uint32_t wmax = wave_max_u32(nrays);
+  if ((threadIdx.x & 63u) == 0) {
+    if (wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+    if (O.tile_cost) atomicMax(O.tile_cost + tile, wmax);
+  }
+}
+
 // Requires n_spp >= 1 and n_bounce >= 1 (the host routes other cases to k_mega_nested).
 template <bool STRICT, bool BVH, bool TEX>
 __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
+  const uint32_t tile = ordered_tile(O);
   uint32_t px, py;
-  pixel_of_thread(px, py);
+  pixel_of_tile(tile, O.tiles_x, px, py);
   uint32_t nrays = 0;
   if (px < P.width && py < P.height && F.count) {
     const size_t pix = (size_t)py * P.width + px;
@@ -144,8 +171,7 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
     O.rgba8[pix] = img;
     O.ids[pix] = id0;
   }
-  uint32_t wsum = wave_sum_u32(nrays);
-  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+  tally_wave(O, tile, nrays);
 }
 
 // BVH scenes: the lanes of a wave need very different numbers of tree steps per path
@@ -234,8 +260,9 @@ __device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search &
 template <bool STRICT, bool TEX>
 __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[kBvhStack * kBlockThreads];
+  const uint32_t tile = ordered_tile(O);
   uint32_t px, py;
-  pixel_of_thread(px, py);
+  pixel_of_tile(tile, O.tiles_x, px, py);
   uint32_t nrays = 0;
   bool active = px < P.width && py < P.height && F.count;
   const size_t pix = active ? (size_t)py * P.width + px : 0;
@@ -326,14 +353,14 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
       }
     }
   }
-  uint32_t wsum = wave_sum_u32(nrays);
-  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+  tally_wave(O, tile, nrays);
 }
 
 template <bool STRICT, bool BVH, bool TEX>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
                                 const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
+  dim3 tiles(O.n_tiles, 1, 1);  // k_mega_regen and k_mega_sched take tiles from a 1-D grid
   dim3 block(256, 1, 1);
   // k_mega_regen and k_mega_sched need at least one sample and one bounce
   static const bool sched = [] {
@@ -343,9 +370,9 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
   if (nested)
     hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX>), grid, block, 0, stream, P, S, F, O);
   else if (BVH && sched)
-    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX>), tiles, block, 0, stream, P, S, F, O);
   else
-    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX>), tiles, block, 0, stream, P, S, F, O);
   return hipGetLastError();
 }
 

@@ -344,6 +344,23 @@ __device__ __forceinline__ void pixel_of_thread(uint32_t &px, uint32_t &py) {
   py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
+// the same layout for a tile picked from a launch-order table
+__device__ __forceinline__ void pixel_of_tile(uint32_t tile, uint32_t tiles_x, uint32_t &px, uint32_t &py) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t wave = t >> 6, lane = t & 63u;
+  px = (tile % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
+  py = (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t other = __shfl_xor(v, off, 64);
+    v = other > v ? other : v;
+  }
+  return v;
+}
+
 // wave-level sum of a 32-bit count, result valid in every lane
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll

@@ -52,6 +52,64 @@ hipError_t launch_expand_triangles(const float *vertices, const uint32_t *indice
   return hipGetLastError();
 }
 
+// Launch order for the next megakernel launch: tiles sorted by descending cost with one
+// counting sort (4096 buckets; costs are scaled down by a power of two when the largest
+// exceeds the bucket range), done by a single block.  Ties land in arbitrary order, which
+// only affects scheduling.  The costs are cleared for the next launch.
+__global__ __launch_bounds__(1024) void k_tile_order(uint32_t *__restrict__ cost,
+                                                     uint32_t *__restrict__ order, uint32_t n) {
+  constexpr uint32_t kBuckets = 4096;
+  __shared__ uint32_t bucket[kBuckets];
+  __shared__ uint32_t partial[1024];
+  __shared__ uint32_t top;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) top = 0;
+  for (uint32_t b = t; b < kBuckets; b += 1024u) bucket[b] = 0;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t i = t; i < n; i += 1024u) m = cost[i] > m ? cost[i] : m;
+  atomicMax(&top, m);
+  __syncthreads();
+  uint32_t shift = 0;
+  while ((top >> shift) >= kBuckets) ++shift;
+  // bucket 0 holds the most expensive tiles
+  for (uint32_t i = t; i < n; i += 1024u) atomicAdd(&bucket[kBuckets - 1u - (cost[i] >> shift)], 1u);
+  __syncthreads();
+  // exclusive prefix over the buckets: four per thread, then across threads
+  uint32_t c[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c[k] = bucket[4u * t + k];
+    sum += c[k];
+  }
+  partial[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024u; off <<= 1) {
+    const uint32_t add = t >= off ? partial[t - off] : 0u;
+    __syncthreads();
+    partial[t] += add;
+    __syncthreads();
+  }
+  uint32_t base = partial[t] - sum;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bucket[4u * t + k] = base;
+    base += c[k];
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < n; i += 1024u) {
+    const uint32_t pos = atomicAdd(&bucket[kBuckets - 1u - (cost[i] >> shift)], 1u);
+    order[pos] = i;
+    cost[i] = 0;
+  }
+}
+
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream) {
+  if (n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_debug_eval(int op, const float *__restrict__ a,
                                                     const float *__restrict__ b,
                                                     float *__restrict__ out, size_t n) {

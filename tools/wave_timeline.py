@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-wave begin/end times of one megakernel launch (needs the RT_EXP_TIMELINE build)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ray_tracer_amd as rt
+w, h = 1920, 1080
+ubo = rt.make_ubo(w, h, 64, 25)
+with rt.Renderer(w, h) as r:
+    r.set_params(ubo); r.set_spheres(rt.default_scene())
+    r.render(0, 1, 1); r.sync()
+    r.render(1, 1, 1); r.sync()
+    ms = r.stats().last_render_ms
+    ids = r.read_primary_ids().reshape(-1)
+n_waves = ((w + 15) // 16) * ((h + 15) // 16) * 4
+rec = ids[:6 * n_waves].reshape(n_waves, 6).astype(np.int64) & 0xffffffff
+t0 = rec[:, 0] | (rec[:, 1] << 32)
+t1 = rec[:, 2] | (rec[:, 3] << 32)
+base = t0.min()
+b = (t0 - base) / 100.0   # microseconds
+e = (t1 - base) / 100.0
+dur = e - b
+print(f"kernel {ms:.3f} ms; waves {n_waves}; span {e.max():.0f} us")
+print("duration us: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
+print("sum of wave durations / (span * 6144 slots) = %.2f" % (dur.sum() / (e.max() * 6144)))
+for q in (0.5, 0.75, 0.9, 0.95, 0.99, 1.0):
+    print(f"  {q:.2f} of waves ended by {np.quantile(e, q):.0f} us")
+act = np.zeros(int(e.max()) + 2)
+for x, y in zip(b.astype(int), e.astype(int)):
+    act[x:y + 1] += 1
+step = max(1, len(act) // 24)
+print("resident waves over time:", " ".join(str(int(act[i:i + step].mean())) for i in range(0, len(act), step)))
+late = np.argsort(-e)[:8]
+for k in late:
+    blk = k // 4
+    print(f"  wave {k} tile ({blk % ((w + 15) // 16)},{blk // ((w + 15) // 16)}) begin {b[k]:.0f} end {e[k]:.0f} dur {dur[k]:.0f} rays {rec[k,4]} slowest lane {rec[k,5]}")
+np.save("gpurun_out/wave_timeline.npy", np.stack([b, e, rec[:, 4], rec[:, 5]], 1))
