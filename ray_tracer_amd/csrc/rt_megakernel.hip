@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
 // chains of samples; they are on the critical path of the launch, so their waves issue
 // ahead of the waves they share a SIMD with.
 #ifndef RT_PRIO_TOP
-#define RT_PRIO_TOP 64   // ranks below n_tiles / RT_PRIO_TOP run at priority 3
+#define RT_PRIO_TOP 16   // ranks below n_tiles / RT_PRIO_TOP run at priority 3
 #endif
 __device__ __forceinline__ uint32_t ordered_tile(const Outputs &O) {
   if (!O.tile_order) return blockIdx.x;
@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
   uint32_t px, py;
   pixel_of_tile(tile, O.tiles_x, px, py);
   uint32_t nrays = 0;
+#ifdef RT_MEASURE_TIMELINE
+  const unsigned long long t_begin = wall_clock64();
+#endif
   if (px < P.width && py < P.height && F.count) {
     const size_t pix = (size_t)py * P.width + px;
     const f3 base = pixel_direction(P, px, py);
@@ -169,9 +172,26 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
     }
     O.accum[pix] = acc;
     O.rgba8[pix] = img;
+#ifndef RT_MEASURE_TIMELINE
     O.ids[pix] = id0;
+#endif
   }
   tally_wave(O, tile, nrays);
+#ifdef RT_MEASURE_TIMELINE
+  // measurement build (tools/wave_timeline.py): per-wave begin and end in 100 MHz ticks,
+  // segments traced and the slowest lane's segments go where the primary ids would
+  const uint32_t wsum = wave_sum_u32(nrays), wmax = wave_max_u32(nrays);
+  if ((threadIdx.x & 63u) == 0) {
+    const unsigned long long t_end = wall_clock64();
+    int *rec = O.ids + 6u * (size_t)(tile * 4u + (threadIdx.x >> 6));
+    rec[0] = (int)(uint32_t)t_begin;
+    rec[1] = (int)(uint32_t)(t_begin >> 32);
+    rec[2] = (int)(uint32_t)t_end;
+    rec[3] = (int)(uint32_t)(t_end >> 32);
+    rec[4] = (int)wsum;
+    rec[5] = (int)wmax;
+  }
+#endif
 }
 
 // BVH scenes: the lanes of a wave need very different numbers of tree steps per path

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave begin/end times of one megakernel launch (needs the RT_EXP_TIMELINE build)."""
+"""Per-wave begin/end times of one megakernel launch (needs a library built with -DRT_MEASURE_TIMELINE, named by RT_HIP_LIB)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,6 +10,7 @@ with rt.Renderer(w, h) as r:
     r.set_params(ubo); r.set_spheres(rt.default_scene())
     r.render(0, 1, 1); r.sync()
     r.render(1, 1, 1); r.sync()
+    r.render(2, 1, 1); r.sync()
     ms = r.stats().last_render_ms
     ids = r.read_primary_ids().reshape(-1)
 n_waves = ((w + 15) // 16) * ((h + 15) // 16) * 4
