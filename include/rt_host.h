@@ -81,6 +81,32 @@ int rt_write_ppm(const char *path, const uint8_t *rgba8, uint32_t width, uint32_
 int rt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height,
                  int flip_y);
 
+/* ---- data formats either side of the path (host only) --------------------------------
+ * The reference links assimp (CMakeLists.txt:12) and stb_image (main.cpp:29-33) for these
+ * and copies the .obj files of assets/models and everything in assets/textures next to the binary
+ * (CMakeLists.txt:78-89), but calls neither on the compute path.  Buffers returned through
+ * out-pointers are malloc'ed; release them with rt_free.  On failure the functions return
+ * -1 and rt_ingest_error() describes why. */
+const char *rt_ingest_error(void);
+void rt_free(void *p);
+
+/* Wavefront OBJ: "v x y z" and "f ..." records (corners "v", "v/vt", "v//vn", "v/vt/vn",
+ * negative = relative indices; polygons are fan-triangulated; everything else is ignored).
+ * Result in the layout rt_set_mesh takes. */
+int rt_load_obj(const char *path, float **out_vertices, uint32_t *out_n_vertices,
+                uint32_t **out_indices, uint32_t *out_n_triangles);
+
+/* Baseline (and extended-sequential Huffman) JPEG, 8 bits, grey or YCbCr with sampling
+ * factors 1 or 2, restart intervals; progressive files are rejected.  Output RGBA8 (alpha
+ * 255), row 0 = top of the picture, or bottom when flip_y != 0 -- what loadTexture asks of
+ * stb with stbi_set_flip_vertically_on_load (main.cpp:1384-1409).  Inverse DCT and chroma
+ * interpolation are done in double precision, so values may differ from libjpeg's integer
+ * pipeline by a level or two. */
+int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgba8,
+                   uint32_t *out_width, uint32_t *out_height);
+int rt_load_jpeg(const char *path, int flip_y, uint8_t **out_rgba8, uint32_t *out_width,
+                 uint32_t *out_height);
+
 #ifdef __cplusplus
 }
 #endif

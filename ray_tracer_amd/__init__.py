@@ -23,6 +23,8 @@ from ._capi import (  # noqa: F401
     TEX_MAP_PLANAR_XZ,
     brick_texture,
     debug_eval,
+    decode_jpeg,
+    load_obj,
     default_scene,
     default_ubo,
     exported_symbols,
@@ -38,5 +40,5 @@ __all__ = [
     "FLAG_ACCUM_LINEAR", "FLAG_COUNT_TRAVERSAL", "FLAG_FORCE_BRUTE", "FLAG_FORCE_BVH", "FLAG_STRICT_MATH",
     "Camera", "Renderer", "RtError", "Stats", "debug_eval", "default_scene", "default_ubo",
     "TEX_MAP_OCTAHEDRAL", "TEX_MAP_PLANAR_XZ", "brick_texture",
-    "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "make_ubo", "matte", "terrain_mesh",
+    "decode_jpeg", "load_obj", "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "make_ubo", "matte", "terrain_mesh",
 ]

@@ -121,6 +121,13 @@ lib.rt_set_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_
 lib.rt_set_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 lib.rt_brick_texture.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
 lib.rt_brick_texture.restype = None
+lib.rt_ingest_error.restype = C.c_char_p
+lib.rt_free.argtypes = [C.c_void_p]
+lib.rt_free.restype = None
+lib.rt_load_obj.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+lib.rt_decode_jpeg.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
 lib.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.rt_sync.argtypes = [C.c_void_p]
 lib.rt_clear.argtypes = [C.c_void_p]
@@ -203,6 +210,37 @@ def brick_texture(width: int = 256, height: int = 256) -> np.ndarray:
     out = np.empty((height, width, 4), dtype=np.uint8)
     lib.rt_brick_texture(width, height, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def load_obj(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """(vertices (n,3) float32, indices (m,3) uint32) of a Wavefront OBJ file."""
+    v, i = C.c_void_p(), C.c_void_p()
+    nv, nt = C.c_uint32(), C.c_uint32()
+    if lib.rt_load_obj(os.fsencode(path), C.byref(v), C.byref(nv), C.byref(i), C.byref(nt)) != 0:
+        raise RtError(-1, lib.rt_ingest_error().decode())
+    try:
+        vertices = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_float)), (nv.value * 3,)).copy() \
+            if nv.value else np.zeros(0, np.float32)
+        indices = np.ctypeslib.as_array(C.cast(i, C.POINTER(C.c_uint32)), (nt.value * 3,)).copy() \
+            if nt.value else np.zeros(0, np.uint32)
+    finally:
+        lib.rt_free(v)
+        lib.rt_free(i)
+    return vertices.reshape(-1, 3), indices.reshape(-1, 3)
+
+
+def decode_jpeg(data: bytes, flip_y: bool = False) -> np.ndarray:
+    """(h, w, 4) uint8 from the bytes of a baseline JPEG file."""
+    out, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+    data = bytes(data)
+    buf = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
+    if lib.rt_decode_jpeg(buf, len(data), int(flip_y), C.byref(out), C.byref(w), C.byref(h)) != 0:
+        raise RtError(-1, lib.rt_ingest_error().decode())
+    try:
+        img = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+    finally:
+        lib.rt_free(out)
+    return img
 
 
 class Renderer:

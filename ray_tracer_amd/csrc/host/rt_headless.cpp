@@ -26,6 +26,9 @@ void usage() {
       "  --sun-focus F --sun-intensity F --defocus F --diverge F\n"
       "  --pitch RAD --yaw RAD       camera orientation;  --rotate dx,dy  applies cameraRotate\n"
       "  --scene default|grid:N      the reference's 3 spheres, or the synthetic N-sphere scene\n"
+      "  --mesh FILE.obj             triangle mesh traced with the spheres (matte grey material)\n"
+      "  --texture bricks|FILE.jpg   albedo texture;  --texture-prims FIRST,COUNT (default: the last sphere)\n"
+      "  --texture-scale S           repeats per world unit (default 0.25);  --texture-map planar|octahedral\n"
       "  --mode megakernel|wavefront|nested   --strict   --linear   --brute   --bvh\n"
       "  --device D                  HIP device ordinal\n"
       "  --out FILE.ppm|FILE.png     shown as the reference's window shows it (bottom row first in memory)\n");
@@ -44,7 +47,10 @@ int main(int argc, char **argv) {
   uint32_t width = 800, height = 608, frames = 1, mode = RT_MODE_MEGAKERNEL, flags = 0;
   int device = 0;
   bool viewport_image = true;
-  std::string scene = "default", out_path;
+  std::string scene = "default", out_path, mesh_path, texture_name;
+  long tex_first = -1, tex_count = 1;
+  float tex_scale = 0.25f;
+  uint32_t tex_map = RT_TEX_MAP_PLANAR_XZ;
   rt_camera camera;
   // main.cpp:624 passes window_width / window_height, an unsigned division, as the aspect
   rt_camera_create(90.0f, (float)(800u / 608u), 0.01f, 10000.0f, &camera);
@@ -77,6 +83,11 @@ int main(int argc, char **argv) {
     else if (a == "--yaw") camera.yaw = (float)std::atof(next());
     else if (a == "--rotate") { have_rot = std::sscanf(next(), "%f,%f", &rot[0], &rot[1]) == 2; }
     else if (a == "--scene") scene = next();
+    else if (a == "--mesh") mesh_path = next();
+    else if (a == "--texture") texture_name = next();
+    else if (a == "--texture-prims") { if (std::sscanf(next(), "%ld,%ld", &tex_first, &tex_count) != 2) { usage(); return 2; } }
+    else if (a == "--texture-scale") tex_scale = (float)std::atof(next());
+    else if (a == "--texture-map") tex_map = std::string(next()) == "octahedral" ? RT_TEX_MAP_OCTAHEDRAL : RT_TEX_MAP_PLANAR_XZ;
     else if (a == "--mode") {
       const std::string m = next();
       mode = m == "wavefront" ? RT_MODE_WAVEFRONT : m == "nested" ? RT_MODE_MEGAKERNEL_NESTED : RT_MODE_MEGAKERNEL;
@@ -117,6 +128,50 @@ int main(int argc, char **argv) {
   if (rt_create(&cfg, &ctx) != RT_OK) return die("rt_create");
   if (rt_set_spheres(ctx, spheres.data(), (uint32_t)spheres.size()) != RT_OK) return die("rt_set_spheres");
 
+  uint32_t n_triangles = 0;
+  if (!mesh_path.empty()) {
+    float *vertices = nullptr;
+    uint32_t *indices = nullptr, n_vertices = 0;
+    if (rt_load_obj(mesh_path.c_str(), &vertices, &n_vertices, &indices, &n_triangles) != 0) {
+      std::fprintf(stderr, "rt_headless: %s: %s\n", mesh_path.c_str(), rt_ingest_error());
+      return 1;
+    }
+    rt_material grey;
+    std::memset(&grey, 0, sizeof grey);
+    grey.colour[0] = grey.colour[1] = grey.colour[2] = 0.7f;
+    grey.specular_colour[0] = grey.specular_colour[1] = grey.specular_colour[2] = 1.0f;
+    const int rc = rt_set_mesh(ctx, vertices, n_vertices, indices, n_triangles, &grey);
+    rt_free(vertices);
+    rt_free(indices);
+    if (rc != RT_OK) return die("rt_set_mesh");
+  }
+  if (!texture_name.empty()) {
+    uint8_t *texels = nullptr;
+    uint32_t tw = 0, th = 0;
+    std::vector<uint8_t> bricks;
+    if (texture_name == "bricks") {
+      tw = th = 1024;
+      bricks.resize((size_t)tw * th * 4);
+      rt_brick_texture(tw, th, bricks.data());
+    } else if (rt_load_jpeg(texture_name.c_str(), 1, &texels, &tw, &th) != 0) {  // flipped, as loadTexture asks of stb
+      std::fprintf(stderr, "rt_headless: %s: %s\n", texture_name.c_str(), rt_ingest_error());
+      return 1;
+    }
+    rt_texture_desc td;
+    std::memset(&td, 0, sizeof td);
+    td.struct_size = sizeof td;
+    td.width = tw;
+    td.height = th;
+    td.flags = RT_TEX_SRGB;
+    td.mapping = tex_map;
+    td.scale_u = td.scale_v = tex_scale;
+    td.first_prim = tex_first >= 0 ? (uint32_t)tex_first : (uint32_t)(spheres.empty() ? 0 : spheres.size() - 1);
+    td.n_prims = (uint32_t)tex_count;
+    const int rc = rt_set_texture(ctx, &td, texels ? texels : bricks.data());
+    rt_free(texels);
+    if (rc != RT_OK) return die("rt_set_texture");
+  }
+
   const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t frame = 0; frame < frames; ++frame) {
     rt_ubo_set_camera(&camera, &ubo);          // main.cpp:697-701
@@ -139,10 +194,10 @@ int main(int argc, char **argv) {
   }
   uint64_t sum = 0;
   for (uint8_t v : pixels) sum += v;
-  std::printf("{\"width\": %u, \"height\": %u, \"frames\": %u, \"spheres\": %zu, \"rays\": %llu, "
+  std::printf("{\"width\": %u, \"height\": %u, \"frames\": %u, \"spheres\": %zu, \"triangles\": %u, \"rays\": %llu, "
               "\"device_ms\": %.3f, \"wall_ms\": %.3f, \"mrays_per_s\": %.1f, \"bvh_nodes\": %u, "
               "\"bvh_build_ms\": %.3f, \"image_byte_sum\": %llu}\n",
-              width, height, frames, spheres.size(), (unsigned long long)st.rays, st.total_render_ms,
+              width, height, frames, spheres.size(), n_triangles, (unsigned long long)st.rays, st.total_render_ms,
               wall_ms, st.total_render_ms > 0 ? st.rays / st.total_render_ms / 1e3 : 0.0, st.bvh_nodes,
               st.last_build_ms, (unsigned long long)sum);
   rt_destroy(ctx);
