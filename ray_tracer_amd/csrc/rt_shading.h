@@ -255,6 +255,9 @@ __device__ __forceinline__ f3 texture_sample(const Texture &T, float u, float v)
 // Sphere: hitPoint = origin + dir*dst, normal = normalize(hitPoint - centre) (:164-165).
 // Triangle: normal = normalize(e1 x e2) turned against the ray.  Returns the id the next
 // segment must skip (the triangle itself) or -1.
+// The normal steers only later segments, never the id of the hit itself, so the fast policy
+// normalises it with the hardware reciprocal square root like the other sampling code.
+template <bool STRICT>
 __device__ __forceinline__ int hit_surface(const Scene &S, int idx, float dst, f3 o, f3 d, f3 &p,
                                            f3 &n, float4 &m_colour, float4 &m_emission,
                                            float4 &m_specular) {
@@ -262,13 +265,13 @@ __device__ __forceinline__ int hit_surface(const Scene &S, int idx, float dst, f
   int mat, skip;
   if ((uint32_t)idx < S.n_spheres) {
     const float4 g = S.geom[idx];
-    n = ieee_normalize(p - mk3(g.x, g.y, g.z));
+    n = Math<STRICT>::normalize(p - mk3(g.x, g.y, g.z));
     mat = idx;
     skip = -1;
   } else {
     const float4 *T = S.tri + 3u * ((uint32_t)idx - S.n_spheres);
     const float4 a0 = T[0], a1 = T[1], a2 = T[2];
-    n = ieee_normalize(cross(mk3(a1.x - a0.x, a1.y - a0.y, a1.z - a0.z),
+    n = Math<STRICT>::normalize(cross(mk3(a1.x - a0.x, a1.y - a0.y, a1.z - a0.z),
                              mk3(a2.x - a0.x, a2.y - a0.y, a2.z - a0.z)));
     if (dot(n, d) > 0.0f) n = mk3(-n.x, -n.y, -n.z);
     mat = (int)S.n_spheres;

@@ -145,7 +145,7 @@ __device__ __forceinline__ int shade_hit(const Scene &S, Hit h, uint32_t &rng, f
                                          f3 &light, f3 &colour) {
   f3 p, n;
   float4 mc, me, ms;
-  const int skip = hit_surface(S, h.idx, h.dst, o, d, p, n, mc, me, ms);
+  const int skip = hit_surface<STRICT>(S, h.idx, h.dst, o, d, p, n, mc, me, ms);
   bool textured = false;
   float tu = 0.0f, tv = 0.0f;
   if constexpr (TEX) {
