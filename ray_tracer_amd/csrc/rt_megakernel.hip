@@ -22,7 +22,7 @@ namespace rt {
 
 // COUNT (only with BVH): also tallies LBVH nodes fetched and spheres tested into
 // O.rays[1] and O.rays[2].
-template <bool STRICT, bool BVH, bool TEX, bool COUNT = false>
+template <bool STRICT, bool BVH, bool TEX, bool APPROX, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t px, py;
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
         int skip = -1;
         for (int b = 0; b < P.n_bounce; ++b) {
           Hit h;
-          if constexpr (COUNT) h = closest_hit_bvh<true>(S, o, d, stack, skip, &cnt_nodes, &cnt_prims);
-          else h = closest_hit<BVH>(S, o, d, stack, skip);
+          if constexpr (COUNT) h = closest_hit_bvh<true, APPROX>(S, o, d, stack, skip, &cnt_nodes, &cnt_prims);
+          else h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
           ++nrays;
           if (s == 0 && b == 0) id0 = h.idx;
           if (h.idx >= 0) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
 }
 
 // Requires n_spp >= 1 and n_bounce >= 1 (the host routes other cases to k_mega_nested).
-template <bool STRICT, bool BVH, bool TEX>
+template <bool STRICT, bool BVH, bool TEX, bool APPROX>
 __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
   const uint32_t tile = ordered_tile(O);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
 
     bool active = true;
     while (active) {
-      Hit h = closest_hit<BVH>(S, o, d, stack, skip);
+      Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
@@ -232,35 +232,37 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
 
 constexpr int kSearchOver = (int)kNullLeaf;  // never a real child reference
 
+template <bool APPROX>
 struct Search {
   int node;  // >= 0 inner node, kSearchOver, otherwise ~leaf position
   int sp;
-  float best_n, a;
+  float a;
   f3 inv_d;
-  Hit best;
+  Closest<APPROX> best;
 };
 
-__device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search &Q) {
-  Q.best.dst = 3.402823466e+38f;
-  Q.best.idx = 0x7fffffff;
-  Q.best_n = __builtin_inff();
+template <bool APPROX>
+__device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search<APPROX> &Q) {
   Q.a = dot(d, d);
+  Q.best.reset(Q.a);
   Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-  for (uint32_t i = 0; i < S.n_large; ++i)
-    sphere_candidate_tie(S.large_geom[i], (int)S.large_prim[i], o, d, Q.a, Q.best_n, Q.best);
+  for (uint32_t i = 0; i < S.n_large; ++i) Q.best.sphere(S.large_geom[i], (int)S.large_prim[i], o, d, Q.a);
   Q.sp = 0;
   if (S.n_spheres + S.n_tris == 1u) Q.node = S.n_large ? kSearchOver : ~0;
   else Q.node = 0;
 }
 
-__device__ __forceinline__ int search_pop(Search &Q, const int *stack) {
+template <bool APPROX>
+__device__ __forceinline__ int search_pop(Search<APPROX> &Q, const int *stack) {
   if (Q.sp == 0) return kSearchOver;
   return stack[(--Q.sp) * kBlockThreads + threadIdx.x];
 }
 
-__device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search &Q, int *stack) {
+template <bool APPROX>
+__device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search<APPROX> &Q, int *stack) {
   const BvhNode nd = S.nodes[Q.node];
-  const float limit = __builtin_fmaf(Q.best.dst, 1.0e-4f, Q.best.dst);
+  const float best_dst = Q.best.dst();
+  const float limit = __builtin_fmaf(best_dst, 1.0e-4f, best_dst);
   const float t0 = slab_entry(nd.lo0, nd.hi0, o, Q.inv_d, limit);
   const float t1 = slab_entry(nd.lo1, nd.hi1, o, Q.inv_d, limit);
   const int c0 = nd.child0, c1 = nd.child1;
@@ -277,7 +279,7 @@ __device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search &
   }
 }
 
-template <bool STRICT, bool TEX>
+template <bool STRICT, bool TEX, bool APPROX>
 __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[kBvhStack * kBlockThreads];
   const uint32_t tile = ordered_tile(O);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
   sample_ray<STRICT>(P, base, rng, o, d);
   f3 light = mk3(0.f, 0.f, 0.f), colour = mk3(1.f, 1.f, 1.f);
   int skip = -1;
-  Search Q;
+  Search<APPROX> Q;
   search_begin(S, o, d, Q);
 
   while (true) {
@@ -322,14 +324,13 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
     } else if (w_leaf >= w_shade) {
       RT_SCHED_TALLY(2, n_leaf);
       if (want_leaf) {
-        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best_n, Q.best);
+        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best);
         Q.node = search_pop(Q, stack);
       }
     } else {
       RT_SCHED_TALLY(3, n_shade);
       if (!want_shade) continue;
-      Hit h = Q.best;
-      if (h.idx == 0x7fffffff) h.idx = -1;
+      const Hit h = Q.best.result();
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
   tally_wave(O, tile, nrays);
 }
 
-template <bool STRICT, bool BVH, bool TEX>
+template <bool STRICT, bool BVH, bool TEX, bool APPROX>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
                                 const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
@@ -388,11 +389,11 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     return !(e && e[0] == '0');
   }();
   if (nested)
-    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX, APPROX>), grid, block, 0, stream, P, S, F, O);
   else if (BVH && sched)
-    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX>), tiles, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX, APPROX>), tiles, block, 0, stream, P, S, F, O);
   else
-    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX>), tiles, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX>), tiles, block, 0, stream, P, S, F, O);
   return hipGetLastError();
 }
 
@@ -400,24 +401,30 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
                                       const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
   if (S.tex)
-    hipLaunchKernelGGL((k_mega_nested<false, true, true, true>), grid, dim3(256), 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<false, true, true, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
   else
-    hipLaunchKernelGGL((k_mega_nested<false, true, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<false, true, false, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
   return hipGetLastError();
 }
 
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
                              const FrameSeq &F, const Outputs &O, hipStream_t stream) {
-  const int variant = (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
+  // fast policy without a mesh: approximate sphere distances behind exact decisions
+  const bool approx = !strict && S.n_tris == 0u;
+  const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
   switch (variant) {
-    case 0: return launch_mega_t<false, false, false>(nested, P, S, F, O, stream);
-    case 1: return launch_mega_t<false, false, true>(nested, P, S, F, O, stream);
-    case 2: return launch_mega_t<false, true, false>(nested, P, S, F, O, stream);
-    case 3: return launch_mega_t<false, true, true>(nested, P, S, F, O, stream);
-    case 4: return launch_mega_t<true, false, false>(nested, P, S, F, O, stream);
-    case 5: return launch_mega_t<true, false, true>(nested, P, S, F, O, stream);
-    case 6: return launch_mega_t<true, true, false>(nested, P, S, F, O, stream);
-    default: return launch_mega_t<true, true, true>(nested, P, S, F, O, stream);
+    case 0: return launch_mega_t<false, false, false, false>(nested, P, S, F, O, stream);
+    case 1: return launch_mega_t<false, false, true, false>(nested, P, S, F, O, stream);
+    case 2: return launch_mega_t<false, true, false, false>(nested, P, S, F, O, stream);
+    case 3: return launch_mega_t<false, true, true, false>(nested, P, S, F, O, stream);
+    case 4: return launch_mega_t<true, false, false, false>(nested, P, S, F, O, stream);
+    case 5: return launch_mega_t<true, false, true, false>(nested, P, S, F, O, stream);
+    case 6: return launch_mega_t<true, true, false, false>(nested, P, S, F, O, stream);
+    case 7: return launch_mega_t<true, true, true, false>(nested, P, S, F, O, stream);
+    case 8: return launch_mega_t<false, false, false, true>(nested, P, S, F, O, stream);
+    case 9: return launch_mega_t<false, false, true, true>(nested, P, S, F, O, stream);
+    case 10: return launch_mega_t<false, true, false, true>(nested, P, S, F, O, stream);
+    default: return launch_mega_t<false, true, true, true>(nested, P, S, F, O, stream);
   }
 }
 

@@ -84,25 +84,6 @@ struct Hit {
   int idx;  // -1: miss
 };
 
-__device__ __forceinline__ void sphere_candidate(float4 g, int i, f3 o, f3 d, float a, float &best_n,
-                                                 Hit &best) {
-  f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
-  float bh = dot(oc, d);
-  float c = dot(oc, oc) - g.w;
-  float disc = __builtin_fmaf(bh, bh, -(a * c));
-  if (disc >= 0.0f && bh <= 0.0f) {
-    float n = -bh - ieee_sqrt(disc);
-    if (n < best_n && n > -1e-30f) {
-      float q = ieee_div(n, a);
-      if (q >= 0.0f && q < best.dst) {
-        best.dst = q;
-        best.idx = i;
-        best_n = n;
-      }
-    }
-  }
-}
-
 // a x b, the second product of each component fused into the difference
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {
   return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
@@ -145,25 +126,147 @@ __device__ __forceinline__ void triangle_candidate(const float4 *__restrict__ T,
   }
 }
 
-// skip: id of the triangle the ray starts on (-1: none); a planar primitive cannot be hit
-// again by a ray that leaves it, and the test above has no epsilon.
-__device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int skip) {
-  Hit best;
-  best.dst = 3.402823466e+38f;
-  best.idx = -1;
-  float best_n = __builtin_inff();
-  float a = dot(d, d);
-  const uint32_t n = S.n_spheres;
-  for (uint32_t i = 0; i < n; ++i) sphere_candidate(S.geom[i], (int)i, o, d, a, best_n, best);
-  if (S.n_tris) {
-    if (best.idx < 0) best.idx = 0x7fffffff;
-    for (uint32_t t = 0; t < S.n_tris; ++t) {
-      const int id = (int)(n + t);
-      if (id != skip) triangle_candidate(S.tri + 3u * t, id, o, d, best_n, best);
+// Exact sphere test with an explicit tie rule, for searches that do not visit primitives in
+// index order (the tree): equal distances go to the lower index, which is what the
+// shader's in-order loop with its strict "<" returns.  In an in-order loop the extra clause
+// never fires, so the brute-force search uses it too.
+__device__ __forceinline__ void sphere_candidate_tie(float4 g, int idx, f3 o, f3 d, float a,
+                                                     float &best_n, Hit &best) {
+  f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+  float bh = dot(oc, d);
+  float c = dot(oc, oc) - g.w;
+  float disc = __builtin_fmaf(bh, bh, -(a * c));
+  if (disc >= 0.0f && bh <= 0.0f) {
+    float n = -bh - ieee_sqrt(disc);
+    if (n <= best_n && n > -1e-30f) {
+      float q = ieee_div(n, a);
+      if (q >= 0.0f && (q < best.dst || (q == best.dst && idx < best.idx))) {
+        best.dst = q;
+        best.idx = idx;
+        best_n = n;
+      }
     }
-    if (best.idx == 0x7fffffff) best.idx = -1;
   }
-  return best;
+}
+
+constexpr int kNoHit = 0x7fffffff;  // "no primitive yet": loses every index tie
+
+// Running closest hit of one search.  APPROX = false: every candidate through the exact
+// tests above.  APPROX = true (fast policy, scenes without triangles): the same DECISIONS,
+// most of them taken on approximate values.  With s' = hardware sqrt(disc) (within 1 ulp)
+// the numerator n' = -bh - s' is within E = 2^-21 (s' + |bh|) of the exactly computed one
+// (four times the worst case), and |bh| >= |n| bounds the numerator itself, so a gap wider
+// than the two candidates' E separates their quotients by more than two ulps.  Hence
+//   n' below -E                the exact numerator is negative: rejected, as the shader does;
+//   n' above best + both E     the exact quotient cannot be smaller: rejected;
+//   n' below best - both E, above its own E, not denormal-small: accepted;
+//   anything else              decided by the exact arithmetic, tie rule included, on this
+//                              candidate and on the current best (kept as bh, disc).
+// By induction the winner is the exact winner, so hit ids do not depend on the policy;
+// only the distance is approximate (n' * rcp(a), about 2 ulp).
+template <bool APPROX>
+struct Closest;
+
+template <>
+struct Closest<false> {
+  Hit best;
+  float best_n;
+  __device__ __forceinline__ void reset(float) {
+    best.dst = 3.402823466e+38f;
+    best.idx = kNoHit;
+    best_n = __builtin_inff();
+  }
+  __device__ __forceinline__ void sphere(float4 g, int idx, f3 o, f3 d, float a) {
+    sphere_candidate_tie(g, idx, o, d, a, best_n, best);
+  }
+  __device__ __forceinline__ void triangle(const float4 *T, int idx, f3 o, f3 d) {
+    triangle_candidate(T, idx, o, d, best_n, best);
+  }
+  __device__ __forceinline__ float dst() const { return best.dst; }
+  __device__ __forceinline__ bool any() const { return best.idx != kNoHit; }
+  __device__ __forceinline__ Hit result() const {
+    Hit h = best;
+    if (h.idx == kNoHit) h.idx = -1;
+    return h;
+  }
+};
+
+template <>
+struct Closest<true> {
+  float n, err;    // approximate numerator of the best so far and its error bound
+  float bh, disc;  // its inputs, for an exact re-evaluation
+  float rcp_a;
+  int idx;
+  __device__ __forceinline__ void reset(float a) {
+    n = __builtin_inff();
+    err = 0.0f;
+    bh = 0.0f;
+    disc = 0.0f;
+    rcp_a = __builtin_amdgcn_rcpf(a);
+    idx = kNoHit;
+  }
+  __device__ __forceinline__ void sphere(float4 g, int i, f3 o, f3 d, float a) {
+    f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
+    const float cbh = dot(oc, d);
+    const float c = dot(oc, oc) - g.w;
+    const float cdisc = __builtin_fmaf(cbh, cbh, -(a * c));
+    if (cdisc >= 0.0f && cbh <= 0.0f) {
+      const float s = __builtin_amdgcn_sqrtf(cdisc);
+      const float cn = -cbh - s;
+      // E plus a floor that keeps denormal-small numerators out of the shortcuts
+      const float cerr = __builtin_fmaf(4.76837158e-7f, s - cbh, 1e-20f);
+      const float band = cerr + err;
+      if (cn < -cerr || cn > n + band) return;
+      bool accept = cn > cerr && cn < n - band;
+      if (!accept) {
+        // too close to call: the exact rule
+        const float ne = -cbh - ieee_sqrt(cdisc);
+        if (ne > -1e-30f) {
+          const float qe = ieee_div(ne, a);
+          if (qe >= 0.0f) {
+            accept = true;
+            if (idx != kNoHit) {
+              const float qb = ieee_div(-bh - ieee_sqrt(disc), a);
+              accept = qe < qb || (qe == qb && i < idx);
+            }
+          }
+        }
+      }
+      if (accept) {
+        n = cn;
+        err = cerr;
+        bh = cbh;
+        disc = cdisc;
+        idx = i;
+      }
+    }
+  }
+  // APPROX kernels are launched only for scenes without a mesh
+  __device__ __forceinline__ void triangle(const float4 *, int, f3, f3) {}
+  __device__ __forceinline__ float dst() const { return idx != kNoHit ? n * rcp_a : 3.402823466e+38f; }
+  __device__ __forceinline__ bool any() const { return idx != kNoHit; }
+  __device__ __forceinline__ Hit result() const {
+    Hit h;
+    h.idx = idx != kNoHit ? idx : -1;
+    h.dst = dst();
+    return h;
+  }
+};
+
+// skip: id of the triangle the ray starts on (-1: none); a planar primitive cannot be hit
+// again by a ray that leaves it, and the triangle test has no epsilon.
+template <bool APPROX>
+__device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int skip) {
+  const float a = dot(d, d);
+  Closest<APPROX> C;
+  C.reset(a);
+  const uint32_t n = S.n_spheres;
+  for (uint32_t i = 0; i < n; ++i) C.sphere(S.geom[i], (int)i, o, d, a);
+  for (uint32_t t = 0; t < S.n_tris; ++t) {
+    const int id = (int)(n + t);
+    if (id != skip) C.triangle(S.tri + 3u * t, id, o, d);
+  }
+  return C.result();
 }
 
 // ---- environment (ray_tracing.comp:239-250) ----------------------------------------

@@ -17,25 +17,6 @@ namespace rt {
 constexpr int kBvhStack = kBvhStackEntries;  // entries per lane; the host checks the tree height
 constexpr int kBlockThreads = 256;
 
-__device__ __forceinline__ void sphere_candidate_tie(float4 g, int idx, f3 o, f3 d, float a,
-                                                     float &best_n, Hit &best) {
-  f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
-  float bh = dot(oc, d);
-  float c = dot(oc, oc) - g.w;
-  float disc = __builtin_fmaf(bh, bh, -(a * c));
-  if (disc >= 0.0f && bh <= 0.0f) {
-    float n = -bh - ieee_sqrt(disc);
-    if (n <= best_n && n > -1e-30f) {
-      float q = ieee_div(n, a);
-      if (q >= 0.0f && (q < best.dst || (q == best.dst && idx < best.idx))) {
-        best.dst = q;
-        best.idx = idx;
-        best_n = n;
-      }
-    }
-  }
-}
-
 // entry distance of the ray into a box, +inf when it misses or the box is beyond limit
 __device__ __forceinline__ float slab_entry(const float lo[3], const float hi[3], f3 o, f3 inv_d,
                                             float limit) {
@@ -47,40 +28,39 @@ __device__ __forceinline__ float slab_entry(const float lo[3], const float hi[3]
   return tn <= tf ? tn : __builtin_inff();
 }
 
-// COUNT adds two per-lane tallies (nodes fetched, spheres tested) for the roofline's
-// bytes-per-segment figure; the search itself is identical.
-// `stack` points at kBvhStack * kBlockThreads ints of LDS owned by the calling kernel
-// (entry-major); it is scratch, so a kernel may reuse that memory between searches.
 // leaf at sorted position pos: a sphere (geometry in leaf order) or a triangle of the mesh
+template <bool APPROX>
 __device__ __forceinline__ void leaf_candidate(const Scene &S, int pos, f3 o, f3 d, float a, int skip,
-                                               float &best_n, Hit &best) {
+                                               Closest<APPROX> &C) {
   const int prim = (int)S.sorted_prim[pos];
   if ((uint32_t)prim < S.n_spheres) {
-    sphere_candidate_tie(S.sorted_geom[pos], prim, o, d, a, best_n, best);
+    C.sphere(S.sorted_geom[pos], prim, o, d, a);
   } else if (prim != skip) {
-    triangle_candidate(S.tri + 3u * ((uint32_t)prim - S.n_spheres), prim, o, d, best_n, best);
+    C.triangle(S.tri + 3u * ((uint32_t)prim - S.n_spheres), prim, o, d);
   }
 }
 
-template <bool COUNT = false>
+// COUNT adds two per-lane tallies (nodes fetched, primitives tested) for the roofline's
+// bytes-per-segment figure; the search itself is identical.
+// `stack` points at kBvhStack * kBlockThreads ints of LDS owned by the calling kernel
+// (entry-major); it is scratch, so a kernel may reuse that memory between searches.
+template <bool COUNT, bool APPROX>
 __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *stack, int skip,
                                                uint32_t *n_nodes = nullptr,
                                                uint32_t *n_prims = nullptr) {
   const int tid = threadIdx.x;
-  Hit best;
-  best.dst = 3.402823466e+38f;
-  best.idx = 0x7fffffff;
-  float best_n = __builtin_inff();
   const float a = dot(d, d);
+  Closest<APPROX> C;
+  C.reset(a);
   const f3 inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
                        __builtin_amdgcn_rcpf(d.z));
   for (uint32_t i = 0; i < S.n_large; ++i) {
-    sphere_candidate_tie(S.large_geom[i], (int)S.large_prim[i], o, d, a, best_n, best);
+    C.sphere(S.large_geom[i], (int)S.large_prim[i], o, d, a);
     if constexpr (COUNT) ++*n_prims;
   }
   if (S.n_spheres + S.n_tris == 1u) {
     if (S.n_large == 0u) {
-      leaf_candidate(S, 0, o, d, a, skip, best_n, best);
+      leaf_candidate(S, 0, o, d, a, skip, C);
       if constexpr (COUNT) ++*n_prims;
     }
   } else {
@@ -89,21 +69,22 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
     while (true) {
       const BvhNode nd = S.nodes[node];
       if constexpr (COUNT) ++*n_nodes;
-      // the distance limit carries slack: box arithmetic rounds, the sphere test decides
-      const float limit = __builtin_fmaf(best.dst, 1.0e-4f, best.dst);
+      // the distance limit carries slack: box arithmetic rounds, the primitive test decides
+      const float best_dst = C.dst();
+      const float limit = __builtin_fmaf(best_dst, 1.0e-4f, best_dst);
       float t0 = slab_entry(nd.lo0, nd.hi0, o, inv_d, limit);
       float t1 = slab_entry(nd.lo1, nd.hi1, o, inv_d, limit);
       int c0 = nd.child0, c1 = nd.child1;
       if (t0 < __builtin_inff() && c0 < 0) {
         if (c0 != kNullLeaf) {
-          leaf_candidate(S, ~c0, o, d, a, skip, best_n, best);
+          leaf_candidate(S, ~c0, o, d, a, skip, C);
           if constexpr (COUNT) ++*n_prims;
         }
         t0 = __builtin_inff();
       }
       if (t1 < __builtin_inff() && c1 < 0) {
         if (c1 != kNullLeaf) {
-          leaf_candidate(S, ~c1, o, d, a, skip, best_n, best);
+          leaf_candidate(S, ~c1, o, d, a, skip, C);
           if constexpr (COUNT) ++*n_prims;
         }
         t1 = __builtin_inff();
@@ -121,15 +102,14 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
       }
     }
   }
-  if (best.idx == 0x7fffffff) best.idx = -1;
-  return best;
+  return C.result();
 }
 
 // closest hit through whichever structure the kernel was built for
-template <bool BVH>
+template <bool BVH, bool APPROX>
 __device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stack, int skip) {
-  if constexpr (BVH) return closest_hit_bvh(S, o, d, stack, skip);
-  else return closest_hit_brute(S, o, d, skip);
+  if constexpr (BVH) return closest_hit_bvh<false, APPROX>(S, o, d, stack, skip);
+  else return closest_hit_brute<APPROX>(S, o, d, skip);
 }
 
 // LDS words a kernel must provide for the traversal stack (1 keeps the array legal)

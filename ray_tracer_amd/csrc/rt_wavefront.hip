@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_wf_init(Params P, uint32_t frame, WfVie
   V.alive[i] = 1;
 }
 
-template <bool BVH>
+template <bool BVH, bool APPROX>
 __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t slot, uint32_t n_pixels,
                                                    int32_t *ids) {
   __shared__ uint32_t lds[kWfE * 4 + 1];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
     if (pix[k] < n_pixels && V.alive[pix[k]]) {
       const float4 p0 = V.P0[pix[k]], p1 = V.P1[pix[k]];
       const int skip = S.n_tris ? __float_as_int(V.P2[pix[k]].w) : -1;
-      const Hit h = closest_hit<BVH>(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), stack, skip);
+      const Hit h = closest_hit<BVH, APPROX>(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), stack, skip);
       V.H[pix[k]] = make_float2(h.dst, __int_as_float(h.idx));
       if (__float_as_uint(p1.w) == 0u) ids[pix[k]] = h.idx;  // sample 0, bounce 0
       is_hit[k] = h.idx >= 0;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels)
 
 // Finishes every pixel of the drain queue in registers: the loop of the regenerating
 // megakernel, resumed from the stored path state, for this one frame.
-template <bool STRICT, bool BVH, bool TEX>
+template <bool STRICT, bool BVH, bool TEX, bool APPROX>
 __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, uint32_t frame,
                                                   Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
     int id0 = -2;
     int skip = __float_as_int(p2.w);
     while (true) {
-      const Hit h = closest_hit<BVH>(S, o, d, stack, skip);
+      const Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
@@ -346,7 +346,7 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
   return 0;
 }
 
-template <bool STRICT, bool BVH, bool TEX>
+template <bool STRICT, bool BVH, bool TEX, bool APPROX>
 static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const Params &P,
                     const Scene &S, uint32_t frame, const Outputs &O, hipStream_t stream,
                     uint32_t *launches, std::string *err) {
@@ -366,12 +366,12 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
     const uint32_t slot = (uint32_t)(it & 3u);
     if (bound <= drain_threshold) {
       hipLaunchKernelGGL(k_wf_compact, dim3(window_blocks), dim3(256), 0, stream, V, n);
-      hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, TEX>), dim3((bound + 255u) / 256u), dim3(256), 0, stream,
+      hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0, stream,
                          P, S, V, frame, O);
       *launches += 2;
       break;
     }
-    hipLaunchKernelGGL((k_wf_extend<BVH>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+    hipLaunchKernelGGL((k_wf_extend<BVH, APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                        O.ids);
     hipLaunchKernelGGL((k_wf_shade<STRICT, TEX>), dim3((bound + kWfChunk - 1u) / kWfChunk + 1u), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
@@ -410,20 +410,25 @@ int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &
   *launches = 0;
   for (uint32_t fi = 0; fi < F.count; ++fi) {
     const uint32_t frame = F.first + fi * F.stride;
-    const int variant = (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
-#define RT_WF_CASE(n, a, b, c)                                                             \
-  case n:                                                                                  \
-    rc = wf_frame<a, b, c>(impl, drain_threshold, P, S, frame, O, stream, launches, err);  \
+    const bool approx = !strict && S.n_tris == 0u;  // see launch_megakernel
+    const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
+#define RT_WF_CASE(n, a, b, c, e)                                                             \
+  case n:                                                                                     \
+    rc = wf_frame<a, b, c, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err);  \
     break;
     switch (variant) {
-      RT_WF_CASE(0, false, false, false)
-      RT_WF_CASE(1, false, false, true)
-      RT_WF_CASE(2, false, true, false)
-      RT_WF_CASE(3, false, true, true)
-      RT_WF_CASE(4, true, false, false)
-      RT_WF_CASE(5, true, false, true)
-      RT_WF_CASE(6, true, true, false)
-      RT_WF_CASE(7, true, true, true)
+      RT_WF_CASE(0, false, false, false, false)
+      RT_WF_CASE(1, false, false, true, false)
+      RT_WF_CASE(2, false, true, false, false)
+      RT_WF_CASE(3, false, true, true, false)
+      RT_WF_CASE(4, true, false, false, false)
+      RT_WF_CASE(5, true, false, true, false)
+      RT_WF_CASE(6, true, true, false, false)
+      RT_WF_CASE(7, true, true, true, false)
+      RT_WF_CASE(8, false, false, false, true)
+      RT_WF_CASE(9, false, false, true, true)
+      RT_WF_CASE(10, false, true, false, true)
+      RT_WF_CASE(11, false, true, true, true)
     }
 #undef RT_WF_CASE
     if (rc) return rc;

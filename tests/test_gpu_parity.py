@@ -611,3 +611,43 @@ def test_headless_driver_with_obj_mesh_and_jpeg_texture(oracle, tmp_path):
     head = f"P6\n{w} {h}\n255\n".encode()
     body = np.frombuffer(data[len(head):], dtype=np.uint8).reshape(h, w, 3)
     assert np.array_equal(body, want["rgba8"][::-1, :, :3])
+
+
+@pytest.mark.parametrize("accel", [rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH])
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT])
+def test_fast_policy_hit_decisions_are_exact_on_near_ties(oracle, mode, accel):
+    """The fast policy takes sphere distances from the hardware sqrt/rcp units but must
+    DECIDE like the exact arithmetic.  Stress: stacks of coincident spheres, spheres whose
+    radii differ by one ulp, shells one ulp apart seen from inside, grazing silhouettes --
+    primary ids (jitter off) must equal the oracle's on every pixel."""
+    w, h = 256, 160
+    ubo = rt.make_ubo(w, h, 1, 2, diverge=0.0)
+    base = rt.default_scene()
+    rows = []
+    for k in range(6):                                   # coincident stack
+        rows.append(base[0].copy())
+    r = np.float32(base[1, 3])
+    for k in range(6):                                   # radii one ulp apart, shuffled order
+        s = base[1].copy()
+        s[3] = np.nextafter(r, np.float32(10.0)) if k % 2 else r
+        rows.append(s)
+    big = base[2].copy()                                 # ground: two shells one ulp apart
+    rows.append(big)
+    big2 = big.copy()
+    big2[3] = np.nextafter(np.float32(big[3]), np.float32(0.0))
+    rows.append(big2)
+    for k in range(8):                                   # a row of touching spheres (grazing pairs)
+        s = base[0].copy()
+        s[:3] = (-3.5 + k, 2.0, -6.0)
+        s[3] = 0.5
+        rows.append(s)
+    for k in range(4):                                   # concentric shells seen from outside
+        s = base[0].copy()
+        s[:3] = (-2.5, 0.0, -4.0)
+        s[3] = np.float32(0.75) if k < 2 else np.nextafter(np.float32(0.75), np.float32(0.0))
+        rows.append(s)
+    sph = np.stack(rows).astype(np.float32)
+    want = oracle.render(ubo, sph, w, h)
+    got = gpu_render(ubo, sph, w, h, mode, accel)       # fast policy
+    assert len(np.unique(want["ids"])) >= 12
+    assert np.array_equal(got["ids"], want["ids"])
