@@ -84,6 +84,10 @@ struct Hit {
   int idx;  // -1: miss
 };
 
+// float4 in the constant address space (memory no kernel of the launch writes)
+typedef __attribute__((address_space(4))) const float4 ConstF4;
+__device__ __forceinline__ float4 load_const(const ConstF4 *p) { return make_float4(p->x, p->y, p->z, p->w); }
+
 // a x b, the second product of each component fused into the difference
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {
   return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
@@ -261,7 +265,18 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int
   Closest<APPROX> C;
   C.reset(a);
   const uint32_t n = S.n_spheres;
-  for (uint32_t i = 0; i < n; ++i) C.sphere(S.geom[i], (int)i, o, d, a);
+  // The scene is read-only for the whole launch.  Reading it through the constant address
+  // space tells the compiler so, and a wave-uniform index then becomes a scalar load (one
+  // fetch per wave through the scalar cache) instead of a vector load of 64 equal addresses.
+  const ConstF4 *geom = (const ConstF4 *)S.geom;
+  // the next sphere is fetched while the current one is tested
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n) g = load_const(geom);
+  for (uint32_t i = 0; i < n; ++i) {
+    const float4 g_next = load_const(geom + (i + 1u < n ? i + 1u : i));
+    C.sphere(g, (int)i, o, d, a);
+    g = g_next;
+  }
   for (uint32_t t = 0; t < S.n_tris; ++t) {
     const int id = (int)(n + t);
     if (id != skip) C.triangle(S.tri + 3u * t, id, o, d);
@@ -380,9 +395,10 @@ __device__ __forceinline__ int hit_surface(const Scene &S, int idx, float dst, f
     mat = (int)S.n_spheres;
     skip = idx;
   }
-  m_colour = S.material[3 * mat + 0];
-  m_emission = S.material[3 * mat + 1];
-  m_specular = S.material[3 * mat + 2];
+  const ConstF4 *material = (const ConstF4 *)S.material;
+  m_colour = load_const(material + 3 * mat + 0);
+  m_emission = load_const(material + 3 * mat + 1);
+  m_specular = load_const(material + 3 * mat + 2);
   return skip;
 }
 
