@@ -246,7 +246,7 @@ __device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search<
   Q.a = dot(d, d);
   Q.best.reset(Q.a);
   Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-  for (uint32_t i = 0; i < S.n_large; ++i) Q.best.sphere(S.large_geom[i], (int)S.large_prim[i], o, d, Q.a);
+  for (uint32_t i = 0; i < S.n_large; ++i) Q.best.sphere(scene_f4(S.large_geom, i), (int)scene_u32(S.large_prim, i), o, d, Q.a);
   Q.sp = 0;
   if (S.n_spheres + S.n_tris == 1u) Q.node = S.n_large ? kSearchOver : ~0;
   else Q.node = 0;
@@ -260,7 +260,7 @@ __device__ __forceinline__ int search_pop(Search<APPROX> &Q, const int *stack) {
 
 template <bool APPROX>
 __device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search<APPROX> &Q, int *stack) {
-  const BvhNode nd = S.nodes[Q.node];
+  const BvhNode nd = load_node(S.nodes, Q.node);
   const float best_dst = Q.best.dst();
   const float limit = __builtin_fmaf(best_dst, 1.0e-4f, best_dst);
   const float t0 = slab_entry(nd.lo0, nd.hi0, o, Q.inv_d, limit);

@@ -86,7 +86,11 @@ struct Hit {
 
 // float4 in the constant address space (memory no kernel of the launch writes)
 typedef __attribute__((address_space(4))) const float4 ConstF4;
+typedef __attribute__((address_space(4))) const uint32_t ConstU32;
 __device__ __forceinline__ float4 load_const(const ConstF4 *p) { return make_float4(p->x, p->y, p->z, p->w); }
+// scene arrays are read-only during a launch: read them through the constant address space
+__device__ __forceinline__ float4 scene_f4(const float4 *p, size_t i) { return load_const((const ConstF4 *)p + i); }
+__device__ __forceinline__ uint32_t scene_u32(const uint32_t *p, size_t i) { return ((const ConstU32 *)p)[i]; }
 
 // a x b, the second product of each component fused into the difference
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {
@@ -106,7 +110,7 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {
 // numerator shortcut of sphere_candidate; a triangle win invalidates it.
 __device__ __forceinline__ void triangle_candidate(const float4 *__restrict__ T, int idx, f3 o, f3 d,
                                                    float &best_n, Hit &best) {
-  const float4 a0 = T[0], a1 = T[1], a2 = T[2];
+  const float4 a0 = scene_f4(T, 0), a1 = scene_f4(T, 1), a2 = scene_f4(T, 2);
   const f3 v0 = mk3(a0.x, a0.y, a0.z);
   const f3 e1 = mk3(a1.x - a0.x, a1.y - a0.y, a1.z - a0.z);
   const f3 e2 = mk3(a2.x - a0.x, a2.y - a0.y, a2.z - a0.z);
@@ -382,13 +386,13 @@ __device__ __forceinline__ int hit_surface(const Scene &S, int idx, float dst, f
   p = fma3(d, dst, o);
   int mat, skip;
   if ((uint32_t)idx < S.n_spheres) {
-    const float4 g = S.geom[idx];
+    const float4 g = scene_f4(S.geom, (uint32_t)idx);
     n = Math<STRICT>::normalize(p - mk3(g.x, g.y, g.z));
     mat = idx;
     skip = -1;
   } else {
     const float4 *T = S.tri + 3u * ((uint32_t)idx - S.n_spheres);
-    const float4 a0 = T[0], a1 = T[1], a2 = T[2];
+    const float4 a0 = scene_f4(T, 0), a1 = scene_f4(T, 1), a2 = scene_f4(T, 2);
     n = Math<STRICT>::normalize(cross(mk3(a1.x - a0.x, a1.y - a0.y, a1.z - a0.z),
                              mk3(a2.x - a0.x, a2.y - a0.y, a2.z - a0.z)));
     if (dot(n, d) > 0.0f) n = mk3(-n.x, -n.y, -n.z);

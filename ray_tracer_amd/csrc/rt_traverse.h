@@ -28,13 +28,25 @@ __device__ __forceinline__ float slab_entry(const float lo[3], const float hi[3]
   return tn <= tf ? tn : __builtin_inff();
 }
 
+// one 64-byte node, read through the constant address space like the rest of the scene
+__device__ __forceinline__ BvhNode load_node(const BvhNode *nodes, int node) {
+  const float4 *p = (const float4 *)(nodes + node);
+  const float4 a = scene_f4(p, 0), b = scene_f4(p, 1), c = scene_f4(p, 2), e = scene_f4(p, 3);
+  BvhNode nd;
+  nd.lo0[0] = a.x; nd.lo0[1] = a.y; nd.lo0[2] = a.z; nd.child0 = __float_as_int(a.w);
+  nd.hi0[0] = b.x; nd.hi0[1] = b.y; nd.hi0[2] = b.z; nd.count0 = __float_as_int(b.w);
+  nd.lo1[0] = c.x; nd.lo1[1] = c.y; nd.lo1[2] = c.z; nd.child1 = __float_as_int(c.w);
+  nd.hi1[0] = e.x; nd.hi1[1] = e.y; nd.hi1[2] = e.z; nd.count1 = __float_as_int(e.w);
+  return nd;
+}
+
 // leaf at sorted position pos: a sphere (geometry in leaf order) or a triangle of the mesh
 template <bool APPROX>
 __device__ __forceinline__ void leaf_candidate(const Scene &S, int pos, f3 o, f3 d, float a, int skip,
                                                Closest<APPROX> &C) {
-  const int prim = (int)S.sorted_prim[pos];
+  const int prim = (int)scene_u32(S.sorted_prim, (uint32_t)pos);
   if ((uint32_t)prim < S.n_spheres) {
-    C.sphere(S.sorted_geom[pos], prim, o, d, a);
+    C.sphere(scene_f4(S.sorted_geom, (uint32_t)pos), prim, o, d, a);
   } else if (prim != skip) {
     C.triangle(S.tri + 3u * ((uint32_t)prim - S.n_spheres), prim, o, d);
   }
@@ -55,7 +67,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
   const f3 inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
                        __builtin_amdgcn_rcpf(d.z));
   for (uint32_t i = 0; i < S.n_large; ++i) {
-    C.sphere(S.large_geom[i], (int)S.large_prim[i], o, d, a);
+    C.sphere(scene_f4(S.large_geom, i), (int)scene_u32(S.large_prim, i), o, d, a);
     if constexpr (COUNT) ++*n_prims;
   }
   if (S.n_spheres + S.n_tris == 1u) {
@@ -67,7 +79,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
     int sp = 0;
     int node = 0;
     while (true) {
-      const BvhNode nd = S.nodes[node];
+      const BvhNode nd = load_node(S.nodes, node);
       if constexpr (COUNT) ++*n_nodes;
       // the distance limit carries slack: box arithmetic rounds, the primitive test decides
       const float best_dst = C.dst();
