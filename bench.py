@@ -88,6 +88,11 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["megakernel", "wavefront", "nested"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo with --rehearse-on-device lets N ranks share one GPU "
+                         "to rehearse the N > 1 control flow (not a measurement)")
+    ap.add_argument("--rehearse-on-device", type=int, default=-1,
+                    help="put every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--images-in-flight", type=int, default=0,
                     help="accumulation images per rank (default: 2 when N > 1, else 1)")
     args = ap.parse_args()
@@ -106,11 +111,16 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.rehearse_on_device >= 0:
+        local_rank = args.rehearse_on_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     mode = {"megakernel": rt.MODE_MEGAKERNEL, "wavefront": rt.MODE_WAVEFRONT,
             "nested": rt.MODE_MEGAKERNEL_NESTED}[args.mode]
@@ -133,10 +143,28 @@ def main() -> None:
     in_flight = [False] * n_buf
     pending = [None] * n_buf
 
+    rehearsal = world > 1 and args.backend == "gloo"
+    small = torch.device("cpu") if rehearsal else dev   # where the scalar all-reduces live
+
+    def begin_sum(a):
+        if not rehearsal:
+            return start_reduce(a, dst=0)
+        # rehearsal: gloo sums a host copy (its CUDA path is not what RCCL will run anyway)
+        host = a.cpu()
+        return (dist.reduce(host, dst=0, op=dist.ReduceOp.SUM, async_op=True), host, a)
+
+    def end_sum(handle) -> None:
+        if not rehearsal:
+            finish_reduce(handle)
+        elif handle is not None:
+            work, host, a = handle
+            work.wait()
+            a.copy_(host)
+
     def retire(k: int) -> None:
         """finish the step that last used image k: its sum, then rank 0's 8-bit image"""
         if in_flight[k]:
-            finish_reduce(pending[k])
+            end_sum(pending[k])
             if rank == 0:
                 renderers[k].resolve()
             in_flight[k], pending[k] = False, None
@@ -147,7 +175,7 @@ def main() -> None:
         accums[k].zero_()
         first, count, stride = frame_partition(i * world, world, rank, world)
         renderers[k].render(first, count, stride)
-        pending[k] = start_reduce(accums[k], dst=0)
+        pending[k] = begin_sum(accums[k])
         in_flight[k] = True
         if n_buf == 1:
             retire(k)
@@ -193,10 +221,10 @@ def main() -> None:
                 t.append(wf.stats().last_render_ms)
             other_ms = sorted(t)[1]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=small)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        t = torch.tensor([rays], dtype=torch.float64, device=dev)
+        t = torch.tensor([rays], dtype=torch.float64, device=small)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_rays = float(t.item())
     else:
@@ -226,9 +254,12 @@ def main() -> None:
                             f"{SPP} spp/frame, maxBounce {BOUNCES}, 1 frame per GPU per step "
                             "(BASELINE.json configs[1])",
                 "mode": args.mode,
-                "math": "fast (hardware transcendentals; geometry IEEE)",
+                "math": "fast (hardware transcendental, sqrt and rcp units in sampling and distances; "
+                        "hit decisions and primary rays exact)",
                 "parallelism": f"frame-split x{world}" + (" + RCCL reduce overlapped with the next frame"
-                                                          if world > 1 else ""),
+                                                          if world > 1 else "") +
+                               (" [REHEARSAL: gloo on host copies, ranks share a device -- not a measurement]"
+                                if rehearsal else ""),
                 "ms_per_frame_1080p_64spp": launch_ms,
                 "rays_per_frame": rays / max(args.steps, 1),
                 "wavefront_ms_per_frame_1080p_64spp": other_ms,
