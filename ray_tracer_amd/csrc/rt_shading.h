@@ -306,8 +306,13 @@ __device__ __forceinline__ f3 environment(const Params &P, f3 d) {
   float g2s = smoothstep_rcp(-0.01f, 100.0f, d.y);                       // edges -0.01, 0
   f3 sky = mix3(mk3(P.horizon[0], P.horizon[1], P.horizon[2]),
                 mk3(P.zenith[0], P.zenith[1], P.zenith[2]), sky_t);
-  float sd = dot(d, mk3(P.sun[0], P.sun[1], P.sun[2]));
-  float sun = M::pow(sd > 0.0f ? sd : 0.0f, P.sun_focus) * P.sun_intensity;
+  // With sunIntensity == 0 (the reference's default, main.cpp:634) and sunFocus > 0 the
+  // power is finite for every direction, so the product is exactly +0: skip the pow.
+  float sun = 0.0f;
+  if (!(P.sun_intensity == 0.0f && P.sun_focus > 0.0f)) {
+    float sd = dot(d, mk3(P.sun[0], P.sun[1], P.sun[2]));
+    sun = M::pow(sd > 0.0f ? sd : 0.0f, P.sun_focus) * P.sun_intensity;
+  }
   f3 comp = mix3(mk3(P.ground[0], P.ground[1], P.ground[2]), sky, g2s);
   float s = sun * (g2s >= 1.0f ? 1.0f : 0.0f);
   return mk3(comp.x + s, comp.y + s, comp.z + s);
