@@ -187,8 +187,10 @@ int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
   if (cfg->struct_size != sizeof(rt_config))
     return fail(RT_ERR_INVALID, "rt_create: struct_size %u, expected %zu", cfg->struct_size,
                 sizeof(rt_config));
-  if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65536u || cfg->height > 65536u)
-    return fail(RT_ERR_INVALID, "rt_create: bad image size %ux%u", cfg->width, cfg->height);
+  if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65536u || cfg->height > 65536u ||
+      (uint64_t)cfg->width * cfg->height > (1ull << 28))
+    return fail(RT_ERR_INVALID, "rt_create: bad image size %ux%u (at most 2^28 pixels)", cfg->width,
+                cfg->height);
   if (cfg->mode > RT_MODE_MEGAKERNEL_NESTED)
     return fail(RT_ERR_INVALID, "rt_create: unknown mode %u", cfg->mode);
   if ((cfg->flags & RT_FLAG_FORCE_BRUTE) && (cfg->flags & RT_FLAG_FORCE_BVH))
@@ -343,12 +345,15 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
   if (count > (1u << 26)) return fail(RT_ERR_INVALID, "rt_set_spheres: %u spheres", count);
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));  // previous launches may still read the old scene
-  if (c->d_geom) RT_HIP(hipFree(c->d_geom));
-  if (c->d_material) RT_HIP(hipFree(c->d_material));
-  c->d_geom = nullptr;
-  c->d_material = nullptr;
-  c->n_spheres = count;
+  // until everything below has succeeded the context holds no scene: a failed upload must
+  // not leave counts that point past freed or unallocated buffers
+  c->have_scene = false;
   c->use_bvh = false;
+  c->n_spheres = 0;
+  if (c->d_geom) RT_HIP(hipFree(c->d_geom));
+  c->d_geom = nullptr;
+  if (c->d_material) RT_HIP(hipFree(c->d_material));
+  c->d_material = nullptr;
   const size_t alloc_n = count ? count : 1;
   RT_HIP(hipMalloc(&c->d_geom, alloc_n * sizeof(float4)));
   RT_HIP(hipMalloc(&c->d_material, ((size_t)count + 1) * 3 * sizeof(float4)));  // + the mesh's
@@ -372,6 +377,7 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
     RT_HIP(hipMemcpy(c->d_material, mat.data(), mat.size() * sizeof(float),
                      hipMemcpyHostToDevice));
   }
+  c->n_spheres = count;
   int rc = rebuild_accel(c);
   if (rc != RT_OK) return rc;
   c->have_scene = true;
@@ -390,9 +396,11 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
                   n_vertices);
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
+  c->have_scene = false;  // restored once the upload has succeeded (see rt_set_spheres)
+  c->use_bvh = false;
+  c->n_tris = 0;
   if (c->d_tri) RT_HIP(hipFree(c->d_tri));
   c->d_tri = nullptr;
-  c->n_tris = n_triangles;
   if (material) std::memcpy(c->mesh_material, material, sizeof c->mesh_material);
   // bounds of the vertices the triangles use (leaf boxes are sized from them)
   for (int k = 0; k < 3; ++k) {
@@ -421,8 +429,13 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_v);
     hipFree(d_i);
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_set_mesh: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+      hipFree(c->d_tri);
+      c->d_tri = nullptr;
+      return fail(RT_ERR_DEVICE, "rt_set_mesh: %s", hipGetErrorString(e));
+    }
   }
+  c->n_tris = n_triangles;
   if (!c->d_material) {  // no spheres uploaded yet: an empty sphere set
     RT_HIP(hipMalloc(&c->d_geom, sizeof(float4)));
     RT_HIP(hipMalloc(&c->d_material, 3 * sizeof(float4)));

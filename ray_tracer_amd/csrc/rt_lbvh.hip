@@ -460,6 +460,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     if (sorted_prim) hipFree(sorted_prim);
     if (sorted_geom) hipFree(sorted_geom);
     nodes = nullptr; sorted_prim = nullptr; sorted_geom = nullptr;
+    capacity = 0;  // stays 0 if an allocation below fails
     BVH_HIP(hipMalloc((void **)&nodes, (size_t)std::max(n - 1, 1u) * sizeof(BvhNode)));
     BVH_HIP(hipMalloc((void **)&sorted_prim, (size_t)n * sizeof(uint32_t)));
     BVH_HIP(hipMalloc((void **)&sorted_geom, (size_t)n * sizeof(float4)));
@@ -474,6 +475,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
   if (n > work->capacity) {
     if (work->slab) hipFree(work->slab);
     work->slab = nullptr;
+    work->capacity = 0;
     const size_t f4 = align256((size_t)n * sizeof(float4)), u4 = align256((size_t)n * sizeof(uint32_t));
     const size_t hist = align256((size_t)256 * nblk * sizeof(uint32_t));
     const size_t total = 5 * f4 + 9 * u4 + hist + 256;
