@@ -89,6 +89,9 @@ struct rt_ctx {
   uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
   uint32_t tiles_x = 0, n_tiles = 0;
   bool order_valid = false, use_tile_order = true;
+  // the order is refreshed after launches 1, 2, 4, 8, then every 16th since the last change
+  // of scene or parameters; in between the costs keep accumulating (atomicMax)
+  uint32_t order_interval = 1, launches_since_order = 0;
 
   // HIP event pairs around each rt_render; resolved lazily so rendering never waits
   struct EventPair {
@@ -297,6 +300,7 @@ int rt_set_params(rt_ctx *c, const void *ubo272) {
   if (!c || !ubo272) return fail(RT_ERR_INVALID, "rt_set_params: null argument");
   rt_ubo u;
   std::memcpy(&u, ubo272, sizeof u);
+  const rt::Params before = c->P;
   rt::Params &P = c->P;
   rt::mat4_inverse(u.view, P.inv_view);
   rt::mat4_inverse(u.projection, P.inv_proj);
@@ -326,6 +330,10 @@ int rt_set_params(rt_ctx *c, const void *ubo272) {
   P.diverge_over_w = P.diverge / P.fwidth;
   P.rcp_w = 1.0f / P.fwidth;
   P.rcp_h = 1.0f / P.fheight;
+  if (!c->have_params || std::memcmp(&before, &P, sizeof P) != 0) {
+    c->order_interval = 1;  // a new view: measure tile costs afresh
+    c->launches_since_order = 0;
+  }
   c->have_params = true;
   if (c->use_bvh && (P.cam_x != c->bvh_cam[0] || P.cam_y != c->bvh_cam[1] || P.cam_z != c->bvh_cam[2])) {
     // leaf boxes are sized from the distance to the camera: rebuild for the new position
@@ -378,6 +386,8 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
                      hipMemcpyHostToDevice));
   }
   c->n_spheres = count;
+  c->order_interval = 1;
+  c->launches_since_order = 0;
   int rc = rebuild_accel(c);
   if (rc != RT_OK) return rc;
   c->have_scene = true;
@@ -436,6 +446,8 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
     }
   }
   c->n_tris = n_triangles;
+  c->order_interval = 1;
+  c->launches_since_order = 0;
   if (!c->d_material) {  // no spheres uploaded yet: an empty sphere set
     RT_HIP(hipMalloc(&c->d_geom, sizeof(float4)));
     RT_HIP(hipMalloc(&c->d_material, 3 * sizeof(float4)));
@@ -547,10 +559,13 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
     }
   }
   if (he == hipSuccess && rc == RT_OK) he = hipEventRecord(ev.end, c->stream);
-  if (he == hipSuccess && rc == RT_OK && ordered) {
-    // what this launch measured becomes the next launch's order (outside the timed pair)
+  if (he == hipSuccess && rc == RT_OK && ordered && ++c->launches_since_order >= c->order_interval) {
+    // what the launches since the last refresh measured becomes the next launch's order
+    // (outside the timed pair)
     he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, c->stream);
     if (he == hipSuccess) c->order_valid = true;
+    c->launches_since_order = 0;
+    if (c->order_interval < 16u) c->order_interval *= 2u;
   }
   if (he != hipSuccess || rc != RT_OK) {
     c->ev_free.push_back(ev);
