@@ -91,6 +91,9 @@ __device__ __forceinline__ float4 load_const(const ConstF4 *p) { return make_flo
 // scene arrays are read-only during a launch: read them through the constant address space
 __device__ __forceinline__ float4 scene_f4(const float4 *p, size_t i) { return load_const((const ConstF4 *)p + i); }
 __device__ __forceinline__ uint32_t scene_u32(const uint32_t *p, size_t i) { return ((const ConstU32 *)p)[i]; }
+__device__ __forceinline__ float scene_f32(const float *p, size_t i) {
+  return ((__attribute__((address_space(4))) const float *)p)[i];
+}
 
 // a x b, the second product of each component fused into the difference
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {
@@ -366,16 +369,20 @@ __device__ __forceinline__ f3 texture_sample(const Texture &T, float u, float v)
   if (ix0 >= W) ix0 = W - 1;
   if (iy0 >= H) iy0 = H - 1;
   const int ix1 = ix0 + 1 == W ? 0 : ix0 + 1, iy1 = iy0 + 1 == H ? 0 : iy0 + 1;
-  const uchar4 c00 = T.texels[(size_t)iy0 * W + ix0], c10 = T.texels[(size_t)iy0 * W + ix1];
-  const uchar4 c01 = T.texels[(size_t)iy1 * W + ix0], c11 = T.texels[(size_t)iy1 * W + ix1];
-  const float *L = T.lut;
-  auto lerp2 = [&](unsigned char a, unsigned char b, unsigned char c, unsigned char d) {
-    const float fa = L[a], fb = L[b], fc = L[c], fd = L[d];
+  // texels as packed words; one channel at a time keeps few values live next to the path state
+  const uint32_t *texels = (const uint32_t *)T.texels;
+  const uint32_t c00 = scene_u32(texels, (size_t)iy0 * W + ix0), c10 = scene_u32(texels, (size_t)iy0 * W + ix1);
+  const uint32_t c01 = scene_u32(texels, (size_t)iy1 * W + ix0), c11 = scene_u32(texels, (size_t)iy1 * W + ix1);
+  float out[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t sh = 8u * (uint32_t)k;
+    const float fa = scene_f32(T.lut, (c00 >> sh) & 255u), fb = scene_f32(T.lut, (c10 >> sh) & 255u);
+    const float fc = scene_f32(T.lut, (c01 >> sh) & 255u), fd = scene_f32(T.lut, (c11 >> sh) & 255u);
     const float top = __builtin_fmaf(fx, fb - fa, fa), bot = __builtin_fmaf(fx, fd - fc, fc);
-    return __builtin_fmaf(fy, bot - top, top);
-  };
-  return mk3(lerp2(c00.x, c10.x, c01.x, c11.x), lerp2(c00.y, c10.y, c01.y, c11.y),
-             lerp2(c00.z, c10.z, c01.z, c11.z));
+    out[k] = __builtin_fmaf(fy, bot - top, top);
+  }
+  return mk3(out[0], out[1], out[2]);
 }
 
 // Hit point, surface normal and material of primitive idx hit at distance dst.
