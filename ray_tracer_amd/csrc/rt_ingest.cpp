@@ -44,7 +44,7 @@ bool corner_index(const char *&p, long n_vertices, uint32_t &out) {
   long v = std::strtol(p, &end, 10);
   if (end == p) return false;
   p = end;
-  while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') ++p;  // skip /vt/vn
+  while (*p && *p != ' ' && *p != '\t' && *p != '\r') ++p;  // skip /vt/vn
   if (v < 0) v = n_vertices + v;  // relative to the vertices read so far
   else v = v - 1;
   if (v < 0 || v >= n_vertices) return false;
@@ -219,6 +219,7 @@ int decode_scan(Decoder &D) {
             int t = D.decode_symbol(D.dc[C.td]);
             if (t < 0 || t > 11) return ingest_fail("jpeg: bad DC code");
             C.pred += Decoder::extend(D.receive(t), t);
+            if (C.pred < -32768 || C.pred > 32767) return ingest_fail("jpeg: DC value out of range");
             coef[0] = C.pred * D.quant[C.tq][0];
             for (int k = 1; k < 64;) {
               int rs = D.decode_symbol(D.ac[C.ta]);
@@ -283,13 +284,14 @@ int rt_load_obj(const char *path, float **out_vertices, uint32_t *out_n_vertices
   bytes.push_back(0);
   std::vector<float> v;
   std::vector<uint32_t> idx;
-  const char *p = (const char *)bytes.data();
+  char *p = (char *)bytes.data();
   long line_no = 0;
   while (*p) {
     ++line_no;
     const char *line = p;
     while (*p && *p != '\n') ++p;
-    const char *next = *p ? p + 1 : p;
+    char *next = *p ? p + 1 : p;
+    *p = 0;  // the number parsers below must not run on into the following line
     while (*line == ' ' || *line == '\t') ++line;
     if (line[0] == 'v' && (line[1] == ' ' || line[1] == '\t')) {
       const char *q = line + 1;
@@ -309,7 +311,7 @@ int rt_load_obj(const char *path, float **out_vertices, uint32_t *out_n_vertices
       std::vector<uint32_t> corners;
       for (;;) {
         while (*q == ' ' || *q == '\t') ++q;
-        if (*q == '\n' || *q == '\r' || *q == 0 || *q == '#') break;
+        if (*q == '\r' || *q == 0 || *q == '#') break;
         uint32_t c;
         if (!corner_index(q, (long)(v.size() / 3), c)) {
           static thread_local char msg[96];
@@ -382,8 +384,9 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
         D.height = D.u16();
         D.width = D.u16();
         D.n_comp = D.u8();
-        if (D.width <= 0 || D.height <= 0 || D.width > 32768 || D.height > 32768)
-          return ingest_fail("jpeg: bad image size");
+        if (D.width <= 0 || D.height <= 0 || D.width > 32768 || D.height > 32768 ||
+            (long long)D.width * D.height > (1ll << 26))
+          return ingest_fail("jpeg: bad image size (at most 2^26 pixels)");
         if (D.n_comp != 1 && D.n_comp != 3) return ingest_fail("jpeg: 1 or 3 components are supported");
         for (int c = 0; c < D.n_comp; ++c) {
           D.comp[c].id = D.u8();
