@@ -651,3 +651,29 @@ def test_fast_policy_hit_decisions_are_exact_on_near_ties(oracle, mode, accel):
     got = gpu_render(ubo, sph, w, h, mode, accel)       # fast policy
     assert len(np.unique(want["ids"])) >= 12
     assert np.array_equal(got["ids"], want["ids"])
+
+
+@pytest.mark.parametrize("scene", ["default", "grid"])
+def test_tile_launch_order_changes_timing_only(scene, monkeypatch):
+    """The megakernels launch the tiles of frame n+1 heaviest-first by the costs frame n
+    measured.  That is scheduling: five progressive frames with the mechanism on and off
+    (RT_TILE_ORDER=0, read when the context is created) give identical bits, fast math."""
+    w, h = 200, 120          # not a multiple of the tile size: partial tiles at two edges
+    ubo = rt.make_ubo(w, h, 4, 12)
+    sph = rt.default_scene() if scene == "default" else rt.grid_spheres_scene(500)
+
+    def run():
+        with rt.Renderer(w, h) as r:
+            r.set_params(ubo)
+            r.set_spheres(sph)
+            for f in range(5):
+                r.render(f, 1, 1)
+            r.sync()
+            return r.read_accum(), r.read_rgba8(), r.read_primary_ids(), r.stats().rays
+
+    monkeypatch.setenv("RT_TILE_ORDER", "1")
+    on = run()
+    monkeypatch.setenv("RT_TILE_ORDER", "0")
+    off = run()
+    assert np.array_equal(_bits(on[0]), _bits(off[0]))
+    assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2]) and on[3] == off[3]
