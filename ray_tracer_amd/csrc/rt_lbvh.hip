@@ -139,13 +139,28 @@ __global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restric
     leaf_lo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
     leaf_hi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
   }
+  // one atomic per block and bound: same-address atomics retire at ~90 per microsecond, so
+  // the grid is kept small (256 blocks) and the four waves of a block combine in LDS first
+  __shared__ float red[2][3][kThreads / 64];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float a = wave_min(mn[k]), b = wave_max(mx[k]);
     if ((threadIdx.x & 63) == 0) {
-      atomicMin(&cbounds[k], f2ord(a));
-      atomicMax(&cbounds[3 + k], f2ord(b));
+      red[0][k][threadIdx.x >> 6] = a;
+      red[1][k][threadIdx.x >> 6] = b;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    float a = red[0][k][0], b = red[1][k][0];
+#pragma unroll
+    for (int wv = 1; wv < kThreads / 64; ++wv) {
+      a = fminf(a, red[0][k][wv]);
+      b = fmaxf(b, red[1][k][wv]);
+    }
+    atomicMin(&cbounds[k], f2ord(a));
+    atomicMax(&cbounds[3 + k], f2ord(b));
   }
 }
 
@@ -203,8 +218,42 @@ __global__ __launch_bounds__(kThreads) void k_rs_hist(const uint32_t *__restrict
   hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];  // digit-major: scan order
 }
 
-// exclusive scan of `total` counters in place, one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *data, uint32_t total) {
+// Exclusive scan of `total` counters in place.  Three launches: every block sums its tile of
+// 2048 counters (coalesced), one block scans the tile sums, every block scans its tile on
+// top of its sum.  (One block walking all 256 * blocks counters took 0.2 ms per radix pass
+// for a million keys, half of the whole build.)
+constexpr uint32_t kScanE = 8;
+constexpr uint32_t kScanTile = kThreads * kScanE;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(v, off, 64);
+    if (lane >= (uint32_t)off) v += up;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_scan_reduce(const uint32_t *__restrict__ data, uint32_t total,
+                                                          uint32_t *__restrict__ tile_sum) {
+  __shared__ uint32_t wsum[kThreads / 64];
+  const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanE;
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kScanE; ++k) sum += first + k < total ? data[first + k] : 0u;
+  const uint32_t inc = wave_inclusive_scan(sum);
+  if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int wv = 0; wv < kThreads / 64; ++wv) t += wsum[wv];
+    tile_sum[blockIdx.x] = t;
+  }
+}
+
+// exclusive scan of a short array in place, one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *data, uint32_t total) {
   __shared__ uint32_t part[1024];
   const uint32_t per = (total + 1023u) / 1024u;
   const uint32_t b = threadIdx.x * per, e = min(b + per, total);
@@ -223,6 +272,28 @@ __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *data, uint32_t total
     const uint32_t c = data[i];
     data[i] = run;
     run += c;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scan_apply(uint32_t *__restrict__ data, uint32_t total,
+                                                         const uint32_t *__restrict__ tile_sum) {
+  __shared__ uint32_t wsum[kThreads / 64];
+  const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanE;
+  uint32_t c[kScanE], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kScanE; ++k) {
+    c[k] = first + k < total ? data[first + k] : 0u;
+    sum += c[k];
+  }
+  const uint32_t inc = wave_inclusive_scan(sum);
+  if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint32_t run = tile_sum[blockIdx.x] + inc - sum;
+  for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) run += wsum[wv];
+#pragma unroll
+  for (uint32_t k = 0; k < kScanE; ++k) {
+    if (first + k < total) data[first + k] = run;
+    run += c[k];
   }
 }
 
@@ -407,7 +478,7 @@ struct Lbvh::Work {
   char *slab = nullptr;
   float4 *cr = nullptr, *leaf_lo = nullptr, *leaf_hi = nullptr, *box_lo = nullptr, *box_hi = nullptr;
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr};
-  uint32_t *hist = nullptr, *stamp = nullptr, *cbounds = nullptr;
+  uint32_t *hist = nullptr, *scan_sums = nullptr, *stamp = nullptr, *cbounds = nullptr;
   int *left = nullptr, *right = nullptr, *parent = nullptr, *leaf_parent = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -478,7 +549,8 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     work->capacity = 0;
     const size_t f4 = align256((size_t)n * sizeof(float4)), u4 = align256((size_t)n * sizeof(uint32_t));
     const size_t hist = align256((size_t)256 * nblk * sizeof(uint32_t));
-    const size_t total = 5 * f4 + 9 * u4 + hist + 256;
+    const size_t sums = align256(((size_t)256 * nblk / kScanTile + 2) * sizeof(uint32_t));
+    const size_t total = 5 * f4 + 9 * u4 + hist + sums + 256;
     BVH_HIP(hipMalloc((void **)&work->slab, total));
     char *p = work->slab;
     auto take = [&](size_t bytes) { char *q = p; p += bytes; return q; };
@@ -497,6 +569,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     work->parent = (int *)take(u4);
     work->leaf_parent = (int *)take(u4);
     work->hist = (uint32_t *)take(hist);
+    work->scan_sums = (uint32_t *)take(sums);
     work->cbounds = (uint32_t *)take(256);
     work->capacity = n;
   }
@@ -586,7 +659,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
   BVH_HIP(hipMemsetAsync(w.cbounds, 0xff, 3 * sizeof(uint32_t), stream));      // running minima
   BVH_HIP(hipMemsetAsync(w.cbounds + 3, 0x00, 3 * sizeof(uint32_t), stream));  // running maxima
   const uint32_t blocks_n = (n + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(k_leaf_boxes, dim3(std::min(blocks_n, 1024u)), dim3(kThreads), 0, stream, w.cr,
+  hipLaunchKernelGGL(k_leaf_boxes, dim3(std::min(blocks_n, 256u)), dim3(kThreads), 0, stream, w.cr,
                      n_spheres, d_tri, n, bp, w.leaf_lo, w.leaf_hi, w.cbounds);
   hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(kThreads), 0, stream, w.leaf_lo, w.leaf_hi, n,
                      w.cbounds, w.keys[0], w.vals[0]);
@@ -594,7 +667,12 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
   for (uint32_t shift = 0; shift < 32; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], n, shift, w.hist,
                        nblk);
-    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, stream, w.hist, 256u * nblk);
+    const uint32_t n_counters = 256u * nblk, scan_tiles = (n_counters + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(scan_tiles), dim3(kThreads), 0, stream, w.hist, n_counters,
+                       w.scan_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, w.scan_sums, scan_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(scan_tiles), dim3(kThreads), 0, stream, w.hist, n_counters,
+                       w.scan_sums);
     hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], w.vals[cur],
                        w.keys[cur ^ 1], w.vals[cur ^ 1], n, shift, w.hist, nblk);
     cur ^= 1;
