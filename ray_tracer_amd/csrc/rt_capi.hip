@@ -400,51 +400,63 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
   if (n_triangles && (!vertices || !indices || !material))
     return fail(RT_ERR_INVALID, "rt_set_mesh: null data");
   if (n_triangles > (1u << 26)) return fail(RT_ERR_INVALID, "rt_set_mesh: %u triangles", n_triangles);
-  for (size_t k = 0; k < (size_t)n_triangles * 3; ++k)
-    if (indices[k] >= n_vertices)
-      return fail(RT_ERR_INVALID, "rt_set_mesh: index %u at position %zu, %u vertices", indices[k], k,
-                  n_vertices);
+  if (n_triangles && n_vertices == 0) return fail(RT_ERR_INVALID, "rt_set_mesh: triangles without vertices");
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
-  c->have_scene = false;  // restored once the upload has succeeded (see rt_set_spheres)
-  c->use_bvh = false;
-  c->n_tris = 0;
-  if (c->d_tri) RT_HIP(hipFree(c->d_tri));
-  c->d_tri = nullptr;
-  if (material) std::memcpy(c->mesh_material, material, sizeof c->mesh_material);
-  // bounds of the vertices the triangles use (leaf boxes are sized from them)
-  for (int k = 0; k < 3; ++k) {
-    c->mesh_lo[k] = 3.0e38f;
-    c->mesh_hi[k] = -3.0e38f;
-  }
+
+  // The new mesh is expanded, checked and measured on the device BEFORE the old one is
+  // dropped, so a rejected upload (index out of range) leaves the context as it was.
+  float4 *new_tri = nullptr;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   if (n_triangles) {
-    std::vector<unsigned char> used(n_vertices, 0);
-    for (size_t k = 0; k < (size_t)n_triangles * 3; ++k) used[indices[k]] = 1;
-    for (uint32_t v = 0; v < n_vertices; ++v)
-      if (used[v])
-        for (int k = 0; k < 3; ++k) {
-          c->mesh_lo[k] = std::min(c->mesh_lo[k], vertices[3 * (size_t)v + k]);
-          c->mesh_hi[k] = std::max(c->mesh_hi[k], vertices[3 * (size_t)v + k]);
-        }
-    // indexed upload, expanded to v0,v1,v2 per triangle on the device
     float *d_v = nullptr;
-    uint32_t *d_i = nullptr;
-    RT_HIP(hipMalloc(&d_v, (size_t)n_vertices * 3 * sizeof(float)));
-    RT_HIP(hipMalloc(&d_i, (size_t)n_triangles * 3 * sizeof(uint32_t)));
-    RT_HIP(hipMalloc(&c->d_tri, (size_t)n_triangles * 3 * sizeof(float4)));
-    hipError_t e = hipMemcpy(d_v, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice);
+    uint32_t *d_i = nullptr, *d_report = nullptr;
+    uint32_t report[7];
+    hipError_t e = hipMalloc(&d_v, (size_t)n_vertices * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_i, (size_t)n_triangles * 3 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_report, sizeof report);
+    if (e == hipSuccess) e = hipMalloc(&new_tri, (size_t)n_triangles * 3 * sizeof(float4));
     if (e == hipSuccess)
-      e = hipMemcpy(d_i, indices, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = rt::launch_expand_triangles(d_v, d_i, n_triangles, c->d_tri, c->stream);
+      e = hipMemcpyAsync(d_v, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(d_i, indices, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                         c->stream);
+    if (e == hipSuccess)
+      e = rt::launch_expand_triangles(d_v, n_vertices, d_i, n_triangles, new_tri, d_report, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(report, d_report, sizeof report, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_v);
     hipFree(d_i);
+    hipFree(d_report);
     if (e != hipSuccess) {
-      hipFree(c->d_tri);
-      c->d_tri = nullptr;
+      hipFree(new_tri);
       return fail(RT_ERR_DEVICE, "rt_set_mesh: %s", hipGetErrorString(e));
     }
+    if (report[0] != 0xffffffffu) {
+      hipFree(new_tri);
+      return fail(RT_ERR_INVALID, "rt_set_mesh: index %u at position %u, %u vertices", indices[report[0]],
+                  report[0], n_vertices);
+    }
+    for (int k = 0; k < 3; ++k) {  // ordered bits back to floats
+      auto back = [](uint32_t u) {
+        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+        float f;
+        std::memcpy(&f, &u, sizeof f);
+        return f;
+      };
+      lo[k] = back(report[1 + k]);
+      hi[k] = back(report[4 + k]);
+    }
   }
+
+  c->have_scene = false;  // restored once everything below has succeeded (see rt_set_spheres)
+  c->use_bvh = false;
+  c->n_tris = 0;
+  if (c->d_tri) RT_HIP(hipFree(c->d_tri));
+  c->d_tri = new_tri;
+  if (material) std::memcpy(c->mesh_material, material, sizeof c->mesh_material);
+  std::memcpy(c->mesh_lo, lo, sizeof lo);
+  std::memcpy(c->mesh_hi, hi, sizeof hi);
   c->n_tris = n_triangles;
   c->order_interval = 1;
   c->launches_since_order = 0;

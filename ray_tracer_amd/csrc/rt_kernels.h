@@ -18,8 +18,10 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
 // rt_util.hip
 hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
                           uint32_t linear_accum, hipStream_t stream);
-hipError_t launch_expand_triangles(const float *vertices, const uint32_t *indices, uint32_t n_tris,
-                                   float4 *tri, hipStream_t stream);
+// expands an indexed mesh to per-triangle vertices; report (7 device words) receives the
+// position of the first out-of-range index (or ~0) and the ordered-bit bounds of the vertices
+hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, const uint32_t *indices,
+                                   uint32_t n_tris, float4 *tri, uint32_t *report, hipStream_t stream);
 // tile costs of the last launch -> heaviest-first launch order; clears the costs
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,

@@ -31,24 +31,90 @@ hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
   return hipGetLastError();
 }
 
-// indexed mesh -> v0, v1, v2 per triangle (one float4 each)
+// order-preserving map float -> uint for atomicMin / atomicMax, and back
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Indexed mesh -> v0, v1, v2 per triangle (one float4 each), checked on the way:
+//   report[0]      position (3 * triangle + corner) of the first index >= n_vertices, or ~0
+//   report[1..3]   minimum x, y, z over the vertices the triangles use (ordered bits)
+//   report[4..6]   maximum
+// A bad index reads vertex 0 instead, so the launch itself is always in bounds.
 __global__ __launch_bounds__(256) void k_expand_triangles(const float *__restrict__ vertices,
+                                                          uint32_t n_vertices,
                                                           const uint32_t *__restrict__ indices,
-                                                          uint32_t n_tris, float4 *__restrict__ tri) {
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= n_tris) return;
+                                                          uint32_t n_tris, float4 *__restrict__ tri,
+                                                          uint32_t *__restrict__ report) {
+  __shared__ float red[2][3][4];
+  __shared__ uint32_t bad_at[4];
+  float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  uint32_t bad = 0xffffffffu;
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tris; t += gridDim.x * 256u) {
 #pragma unroll
-  for (int v = 0; v < 3; ++v) {
-    const float *p = vertices + 3u * (size_t)indices[3u * t + v];
-    tri[3u * t + v] = make_float4(p[0], p[1], p[2], 0.f);
+    for (int v = 0; v < 3; ++v) {
+      uint32_t idx = indices[3u * t + v];
+      if (idx >= n_vertices) {
+        bad = bad < 3u * t + v ? bad : 3u * t + v;
+        idx = 0;
+      }
+      const float *p = vertices + 3u * (size_t)idx;
+      const float x = p[0], y = p[1], z = p[2];
+      tri[3u * t + v] = make_float4(x, y, z, 0.f);
+      mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+      mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+  }
+  // wave, then block, then one atomic per block and value
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+    }
+    const uint32_t other = __shfl_xor(bad, off, 64);
+    bad = other < bad ? other : bad;
+  }
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      red[0][k][wave] = mn[k];
+      red[1][k][wave] = mx[k];
+    }
+    bad_at[wave] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    float a = red[0][k][0], b = red[1][k][0];
+    for (int wv = 1; wv < 4; ++wv) {
+      a = fminf(a, red[0][k][wv]);
+      b = fmaxf(b, red[1][k][wv]);
+    }
+    atomicMin(report + 1 + k, ordered_bits(a));
+    atomicMax(report + 4 + k, ordered_bits(b));
+  } else if (threadIdx.x == 3) {
+    uint32_t m = bad_at[0];
+    for (int wv = 1; wv < 4; ++wv) m = bad_at[wv] < m ? bad_at[wv] : m;
+    if (m != 0xffffffffu) atomicMin(report, m);
   }
 }
 
-hipError_t launch_expand_triangles(const float *vertices, const uint32_t *indices, uint32_t n_tris,
-                                   float4 *tri, hipStream_t stream) {
+// report: 7 words of device memory; initialised here
+hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, const uint32_t *indices,
+                                   uint32_t n_tris, float4 *tri, uint32_t *report, hipStream_t stream) {
   if (n_tris == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_expand_triangles, dim3((n_tris + 255u) / 256u), dim3(256), 0, stream, vertices,
-                     indices, n_tris, tri);
+  hipError_t e = hipMemsetAsync(report, 0xff, 4 * sizeof(uint32_t), stream);   // bad position, minima
+  if (e == hipSuccess) e = hipMemsetAsync(report + 4, 0x00, 3 * sizeof(uint32_t), stream);  // maxima
+  if (e != hipSuccess) return e;
+  uint32_t blocks = (n_tris + 255u) / 256u;
+  if (blocks > 256u) blocks = 256u;
+  hipLaunchKernelGGL(k_expand_triangles, dim3(blocks), dim3(256), 0, stream, vertices, n_vertices, indices,
+                     n_tris, tri, report);
   return hipGetLastError();
 }
 
