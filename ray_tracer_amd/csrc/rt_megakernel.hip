@@ -237,7 +237,7 @@ struct Search {
   int node;  // >= 0 inner node, kSearchOver, otherwise ~leaf position
   int sp;
   float a;
-  f3 inv_d;
+  f3 inv_d, oi;  // 1 / d and o / d
   Closest<APPROX> best;
 };
 
@@ -246,6 +246,7 @@ __device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search<
   Q.a = dot(d, d);
   Q.best.reset(Q.a);
   Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+  Q.oi = mk3(o.x * Q.inv_d.x, o.y * Q.inv_d.y, o.z * Q.inv_d.z);
   for (uint32_t i = 0; i < S.n_large; ++i) Q.best.sphere(scene_f4(S.large_geom, i), (int)scene_u32(S.large_prim, i), o, d, Q.a);
   Q.sp = 0;
   if (S.n_spheres + S.n_tris == 1u) Q.node = S.n_large ? kSearchOver : ~0;
@@ -259,12 +260,12 @@ __device__ __forceinline__ int search_pop(Search<APPROX> &Q, const int *stack) {
 }
 
 template <bool APPROX>
-__device__ __forceinline__ void search_inner_step(const Scene &S, f3 o, Search<APPROX> &Q, int *stack) {
+__device__ __forceinline__ void search_inner_step(const Scene &S, Search<APPROX> &Q, int *stack) {
   const BvhNode nd = load_node(S.nodes, Q.node);
   const float best_dst = Q.best.dst();
   const float limit = __builtin_fmaf(best_dst, 1.0e-4f, best_dst);
-  const float t0 = slab_entry(nd.lo0, nd.hi0, o, Q.inv_d, limit);
-  const float t1 = slab_entry(nd.lo1, nd.hi1, o, Q.inv_d, limit);
+  const float t0 = slab_entry(nd.lo0, nd.hi0, Q.oi, Q.inv_d, limit);
+  const float t1 = slab_entry(nd.lo1, nd.hi1, Q.oi, Q.inv_d, limit);
   const int c0 = nd.child0, c1 = nd.child1;
   const bool go0 = t0 < __builtin_inff() && c0 != (int)kNullLeaf;
   const bool go1 = t1 < __builtin_inff() && c1 != (int)kNullLeaf;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
               w_shade = n_shade * RT_SCHED_W_SHADE;
     if (w_inner >= w_leaf && w_inner >= w_shade) {
       RT_SCHED_TALLY(1, n_inner);
-      if (want_inner) search_inner_step(S, o, Q, stack);
+      if (want_inner) search_inner_step(S, Q, stack);
     } else if (w_leaf >= w_shade) {
       RT_SCHED_TALLY(2, n_leaf);
       if (want_leaf) {
