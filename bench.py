@@ -76,9 +76,9 @@ def pmc_traffic_bytes():
     try:
         with open(path) as f:
             d = json.load(f)
-        return float(d["hbm_bytes_per_launch"]), d.get("source", path)
+        return float(d["hbm_bytes_per_launch"]), d.get("source", path), d
     except Exception:
-        return None, None
+        return None, None, {}
 
 
 def main() -> None:
@@ -235,7 +235,7 @@ def main() -> None:
         launch_ms = kernel_ms / max(args.steps, 1)          # rank 0's render launches, HIP events
         flops = algorithmic_flops(rays, samples, n_spheres) / max(args.steps, 1)
         achieved = flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes() if args.mode == "megakernel" else (None, None)
+        traffic, traffic_src, pmc = pmc_traffic_bytes() if args.mode == "megakernel" else (None, None, {})
         out = {
             "metric": "Mrays/sec (all bounces)",
             "value": total_rays / elapsed / 1e6,
@@ -274,6 +274,10 @@ def main() -> None:
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                # from the same committed counter passes: share of the launch the vector ALUs were
+                # issuing, and share of the 64 lanes active per issued instruction
+                "valu_busy": pmc.get("valu_busy"),
+                "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
                 "launch_ms": launch_ms,
                 "algorithmic_flops_per_launch": flops,
                 "note": "branchy FP32 vector work, no dense contraction: priced against the FP32 "
