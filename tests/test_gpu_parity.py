@@ -677,3 +677,60 @@ def test_tile_launch_order_changes_timing_only(scene, monkeypatch):
     off = run()
     assert np.array_equal(_bits(on[0]), _bits(off[0]))
     assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2]) and on[3] == off[3]
+
+
+# ---------------------------------------------------------------- the benchmark's own size
+def test_full_size_properties_1080p_64spp(oracle):
+    """BASELINE.json configs[1] at full size (1920x1080, 64 spp, 25 bounces), fast math, through
+    properties that do not need a 200-M-ray CPU render:
+      * primary ids equal the oracle's on all 2,073,600 pixels (the oracle needs one segment
+        of one sample per pixel for that);
+      * the three kernel organisations trace the same paths: identical ray counts and
+        bit-identical accumulation images;
+      * the frame count channel is 1 everywhere, no value is NaN or negative;
+      * rendering the frame a second time into the same accumulation doubles it exactly
+        (same frame index, so the same paths: x + x is exact in binary floating point);
+      * sky pixels whose every sample misses carry exactly 64 segments: total rays are
+        bounded by samples <= rays <= samples * bounces."""
+    w, h, spp, bounces = 1920, 1080, 64, 25
+    ubo = rt.make_ubo(w, h, spp, bounces)
+    sph = rt.default_scene()
+    probe = rt.make_ubo(w, h, 1, 1)
+    want_ids = oracle.render(probe, sph, w, h, threads=8)["ids"]
+    results = []
+    for mode in (rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT):
+        with rt.Renderer(w, h, mode=mode) as r:
+            r.set_params(ubo)
+            r.set_spheres(sph)
+            r.render(0, 1, 1)
+            acc = r.read_accum()
+            ids = r.read_primary_ids()
+            rays = r.stats().rays
+            if mode == rt.MODE_MEGAKERNEL:
+                r.render(0, 1, 1)                 # now with the tile order the first launch measured
+                twice = r.read_accum()
+                assert np.array_equal(_bits(twice), _bits(acc + acc))
+                assert r.stats().rays == 2 * rays
+        results.append((acc, ids, rays))
+    acc, ids, rays = results[0]
+    # default jitter moves sample 0's primary ray: silhouette pixels may differ, counted
+    assert (ids != want_ids).mean() <= 1e-4
+    assert np.isfinite(acc).all() and (acc >= 0).all() and (acc[..., 3] == 1.0).all()
+    assert w * h * spp <= rays <= w * h * spp * bounces
+    for other_acc, other_ids, other_rays in results[1:]:
+        assert other_rays == rays
+        assert np.array_equal(other_ids, ids)
+        assert np.array_equal(_bits(other_acc), _bits(acc))
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (3840, 2160)])
+def test_full_size_primary_ids_exact_without_jitter(oracle, size):
+    """Every pixel of a full-size image, fast math, jitter off: ids bit-exact, no exceptions."""
+    w, h = size
+    ubo = rt.make_ubo(w, h, 1, 1, diverge=0.0)
+    sph = rt.default_scene()
+    want = oracle.render(ubo, sph, w, h, threads=8)
+    for mode in (rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT):
+        got = gpu_render(ubo, sph, w, h, mode, 0)
+        assert np.array_equal(got["ids"], want["ids"])
+        assert got["rays"] == want["rays"] == w * h
