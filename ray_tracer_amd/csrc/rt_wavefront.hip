@@ -45,11 +45,11 @@ struct WfView {
   uint32_t *counts;  // [4 slots][4]: -, hit, miss, -; [16]: length of the drain queue
 };
 
-constexpr int kWfE = 4;                    // queue entries per thread
+constexpr int kWfE = 8;                    // queue entries per thread
 constexpr uint32_t kWfChunk = 256u * kWfE;  // queue entries per block
 
 // Appends v[k] to queue q for every (lane, k) with take[k] set.  Ballots rank the lanes
-// of each wave, a 16-entry scan in LDS ranks the (k, wave) groups, and ONE atomic per
+// of each wave, a scan over the kWfE x 4 (k, wave) groups in LDS ranks those, and ONE atomic per
 // block reserves the output range.  Must be reached by every thread of the block.
 __device__ __forceinline__ void block_push(const bool (&take)[kWfE], const uint32_t (&v)[kWfE],
                                            uint32_t *q, uint32_t *count, uint32_t *lds) {
