@@ -244,6 +244,12 @@ def test_empty_scene_renders_sky(oracle):
 def test_error_paths():
     with pytest.raises(rt.RtError):
         rt.Renderer(0, 10)
+    with pytest.raises(rt.RtError):
+        rt.Renderer(65536, 8192)              # 2^29 pixels: above the 2^28 cap
+    with pytest.raises(rt.RtError):
+        rt.Renderer(16, 16, mode=7)
+    with pytest.raises(rt.RtError):
+        rt.Renderer(16, 16, flags=rt.FLAG_FORCE_BRUTE | rt.FLAG_FORCE_BVH)
     with rt.Renderer(16, 16) as r:
         with pytest.raises(rt.RtError) as e:
             r.render(0, 1, 1)
@@ -256,6 +262,27 @@ def test_error_paths():
             r.render(0, 1, 0)
         r.render(0, 1, 1)
         r.sync()
+        # a rejected mesh leaves the scene as it was
+        before = r.read_accum()
+        with pytest.raises(rt.RtError):
+            r.set_mesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 3]], np.uint32), rt.matte(1, 1, 1))
+        r.clear()
+        r.render(0, 1, 1)
+        assert np.array_equal(_bits(r.read_accum()), _bits(before))
+        assert r.stats().bvh_nodes == 0
+
+
+def test_image_sizes_around_the_tile_grid(oracle):
+    """One pixel, one row, one column, a size one short of and one past a tile multiple."""
+    sph = rt.default_scene()
+    for w, h in ((1, 1), (1, 37), (41, 1), (15, 17), (33, 31)):
+        ubo = rt.make_ubo(w, h, 2, 5)
+        want = oracle.render(ubo, sph, w, h, 0, 2, 1)
+        for mode in (rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT):
+            got = gpu_render(ubo, sph, w, h, mode, rt.FLAG_STRICT_MATH, 0, 2, 1)
+            assert np.array_equal(got["ids"], want["ids"])
+            assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+            assert np.array_equal(got["rgba8"], want["rgba8"])
 
 
 # ---------------------------------------------------------------- LBVH
