@@ -10,18 +10,21 @@
 //   T  = sum over samples.xyz, -    H  = (dst, sphere index) of the last extend
 //   alive = 1 while the pixel still has samples to trace in this frame
 // One iteration = two launches:
-//   extend  walks the PIXELS in order (1024 consecutive pixels per block), traces the
-//           live ones, stores H, and splits them into a hit queue and a miss queue
-//           (ballot ranks + one atomic per block and queue)
-//   shade   blocks [0, ceil(hits/1024)) scatter the hit queue, the remaining blocks
-//           light the miss queue and start the pixel's next sample
-// Queue counters rotate through four slots so no launch ever resets a counter another
-// launch of the same iteration still reads.
+//   extend  walks the PIXELS in order (2048 consecutive pixels per block), traces the
+//           live ones, stores H, and sorts the block's live pixels into ITS OWN slice of
+//           the queue: hits packed from the front, misses from the back (ballot ranks and
+//           an LDS scan; no global atomic decides a position)
+//   shade   block b reads slice b: its leading waves scatter the hits, its trailing
+//           waves light the misses and start the pixel's next sample; at most two waves
+//           of a block see both kinds
+// The totals the host polls rotate through four slots so no launch ever resets a counter
+// another launch of the same iteration still reads.
 //
 // Three measured facts shape the kernels.  (1) Returning atomics on ONE counter retire
 // at ~90 per microsecond chip-wide, so a push per wave (32k waves per launch at 1080p)
-// costs more than the stage's arithmetic: every thread handles kWfE entries and a block
-// reserves its output range with a single atomic per queue.  (2) A queue that is itself
+// costs more than the stage's arithmetic; even one push per block and queue (4,050 per
+// launch) held the extend stage at 54 us.  Hence the per-block queue slices above: the only
+// atomics left are two fire-and-forget additions per block for the totals.  (2) A queue that is itself
 // compacted from queue order drifts into a random permutation of the pixels after a few
 // dozen iterations, and 16-byte gathers from random lines cost 3x the time of the
 // first, ordered iteration; walking pixels in order keeps every queue chunk inside a
@@ -41,18 +44,20 @@ struct WfView {
   float4 *P0, *P1, *P2, *P3, *T;
   float2 *H;
   unsigned char *alive;
-  uint32_t *q_hit, *q_miss;
-  uint32_t *counts;  // [4 slots][4]: -, hit, miss, -; [16]: length of the drain queue
+  uint32_t *q;       // one slice of kWfChunk entries per extend block; also the drain queue
+  uint2 *slice;      // per extend block: hits at the front, misses at the back of its slice
+  uint32_t *counts;  // [4 slots][4]: -, hits, misses, - (totals); [16]: length of the drain queue
 };
 
 constexpr int kWfE = 8;                    // queue entries per thread
 constexpr uint32_t kWfChunk = 256u * kWfE;  // queue entries per block
 
-// Appends v[k] to queue q for every (lane, k) with take[k] set.  Ballots rank the lanes
-// of each wave, a scan over the kWfE x 4 (k, wave) groups in LDS ranks those, and ONE atomic per
-// block reserves the output range.  Must be reached by every thread of the block.
-__device__ __forceinline__ void block_push(const bool (&take)[kWfE], const uint32_t (&v)[kWfE],
-                                           uint32_t *q, uint32_t *count, uint32_t *lds) {
+// Ranks the entries (lane, k) with take[k] set in (k, wave, lane) order: off[k] is the
+// position of this thread's k-th entry among them, the return value their number.
+// Ballots rank the lanes of each wave, a scan over the kWfE x 4 (k, wave) groups in LDS
+// ranks those.  Must be reached by every thread of the block; lds holds kWfE * 4 + 1 words.
+__device__ __forceinline__ uint32_t block_rank(const bool (&take)[kWfE], uint32_t (&off)[kWfE],
+                                               uint32_t *lds) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t rank[kWfE];
 #pragma unroll
@@ -70,14 +75,29 @@ __device__ __forceinline__ void block_push(const bool (&take)[kWfE], const uint3
       lds[j] = run;
       run += c;
     }
-    lds[kWfE * 4] = run ? atomicAdd(count, run) : 0u;
+    lds[kWfE * 4] = run;
   }
   __syncthreads();
-  const uint32_t base = lds[kWfE * 4];
+  const uint32_t total = lds[kWfE * 4];
+#pragma unroll
+  for (int k = 0; k < kWfE; ++k) off[k] = lds[k * 4 + wave] + rank[k];
+  __syncthreads();
+  return total;
+}
+
+// Appends v[k] to the global queue q for every entry with take[k] set: block_rank plus ONE
+// returning atomic per block for the output range (used once per frame, by k_wf_compact).
+__device__ __forceinline__ void block_push(const bool (&take)[kWfE], const uint32_t (&v)[kWfE],
+                                           uint32_t *q, uint32_t *count, uint32_t *lds) {
+  __shared__ uint32_t base_slot;
+  uint32_t off[kWfE];
+  const uint32_t total = block_rank(take, off, lds);
+  if (threadIdx.x == 0) base_slot = total ? atomicAdd(count, total) : 0u;
+  __syncthreads();
+  const uint32_t base = base_slot;
 #pragma unroll
   for (int k = 0; k < kWfE; ++k)
-    if (take[k]) q[base + lds[k * 4 + wave] + rank[k]] = v[k];
-  __syncthreads();
+    if (take[k]) q[base + off[k]] = v[k];
 }
 
 template <bool STRICT>
@@ -125,8 +145,22 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
       is_miss[k] = !is_hit[k];
     }
   }
-  block_push(is_hit, pix, V.q_hit, cnt + 1, lds);
-  block_push(is_miss, pix, V.q_miss, cnt + 2, lds);
+  // this block's slice of the queue: hits from the front, misses from the back
+  uint32_t off[kWfE];
+  uint32_t *slice = V.q + first;
+  const uint32_t n_hit = block_rank(is_hit, off, lds);
+#pragma unroll
+  for (int k = 0; k < kWfE; ++k)
+    if (is_hit[k]) slice[off[k]] = pix[k];
+  const uint32_t n_miss = block_rank(is_miss, off, lds);
+#pragma unroll
+  for (int k = 0; k < kWfE; ++k)
+    if (is_miss[k]) slice[kWfChunk - n_miss + off[k]] = pix[k];
+  if (threadIdx.x == 0) {
+    V.slice[blockIdx.x] = make_uint2(n_hit, n_miss);
+    if (n_hit) atomicAdd(cnt + 1, n_hit);    // totals for the host; nobody waits on them
+    if (n_miss) atomicAdd(cnt + 2, n_miss);
+  }
 }
 
 // A path ended with radiance `light`: fold it into the pixel's sample sum and either
@@ -161,59 +195,51 @@ __device__ __forceinline__ bool path_end(const Params &P, const WfView &V, const
 template <bool STRICT, bool TEX>
 __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, uint32_t slot,
                                                   uint32_t frame, Outputs O) {
-  const uint32_t *cnt = V.counts + 4u * (slot & 3u);
-  const uint32_t n_hit = cnt[1], n_miss = cnt[2];
-  const uint32_t hit_blocks = (n_hit + kWfChunk - 1u) / kWfChunk;
-  const uint32_t miss_blocks = (n_miss + kWfChunk - 1u) / kWfChunk;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && (n_hit + n_miss))
-    atomicAdd(O.rays, (unsigned long long)(n_hit + n_miss));
-  if (blockIdx.x >= hit_blocks + miss_blocks) return;
-  if (blockIdx.x < hit_blocks) {
-#pragma unroll
-    for (int k = 0; k < kWfE; ++k) {
-      const uint32_t qi = blockIdx.x * kWfChunk + (uint32_t)k * 256u + threadIdx.x;
-      if (qi < n_hit) {
-        const uint32_t px = V.q_hit[qi];
-        const float4 p0 = V.P0[px], p1 = V.P1[px], p2 = V.P2[px], p3 = V.P3[px];
-        const float2 hrec = V.H[px];
-        const int idx = __float_as_int(hrec.y);
-        uint32_t rng = __float_as_uint(p0.w);
-        const uint32_t sb = __float_as_uint(p1.w);
-        uint32_t s = sb >> 16, b = sb & 0xffffu;
-        f3 o = mk3(p0.x, p0.y, p0.z), d = mk3(p1.x, p1.y, p1.z);
-        f3 colour = mk3(p2.x, p2.y, p2.z), light = mk3(p3.x, p3.y, p3.z);
-        Hit h;
-        h.dst = hrec.x;
-        h.idx = idx;
-        const int skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
-        ++b;
-        if (b >= (uint32_t)P.n_bounce) {
-          path_end<STRICT>(P, V, O, frame, px, rng, s, light);
-        } else {
-          V.P0[px] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
-          V.P1[px] = make_float4(d.x, d.y, d.z, __uint_as_float((s << 16) | b));
-          V.P2[px] = make_float4(colour.x, colour.y, colour.z, __int_as_float(skip));
-          V.P3[px] = make_float4(light.x, light.y, light.z, 0.f);
-        }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t *cnt = V.counts + 4u * (slot & 3u);
+    const uint32_t traced = cnt[1] + cnt[2];
+    if (traced) atomicAdd(O.rays, (unsigned long long)traced);
+  }
+  const uint2 fill = V.slice[blockIdx.x];
+  const uint32_t n_hit = fill.x, first_miss = kWfChunk - fill.y;
+  const uint32_t *slice = V.q + blockIdx.x * kWfChunk;
+#pragma unroll 2
+  for (int k = 0; k < kWfE; ++k) {
+    const uint32_t e = (uint32_t)k * 256u + threadIdx.x;
+    if (e < n_hit) {
+      const uint32_t px = slice[e];
+      const float4 p0 = V.P0[px], p1 = V.P1[px], p2 = V.P2[px], p3 = V.P3[px];
+      const float2 hrec = V.H[px];
+      const int idx = __float_as_int(hrec.y);
+      uint32_t rng = __float_as_uint(p0.w);
+      const uint32_t sb = __float_as_uint(p1.w);
+      uint32_t s = sb >> 16, b = sb & 0xffffu;
+      f3 o = mk3(p0.x, p0.y, p0.z), d = mk3(p1.x, p1.y, p1.z);
+      f3 colour = mk3(p2.x, p2.y, p2.z), light = mk3(p3.x, p3.y, p3.z);
+      Hit h;
+      h.dst = hrec.x;
+      h.idx = idx;
+      const int skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+      ++b;
+      if (b >= (uint32_t)P.n_bounce) {
+        path_end<STRICT>(P, V, O, frame, px, rng, s, light);
+      } else {
+        V.P0[px] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+        V.P1[px] = make_float4(d.x, d.y, d.z, __uint_as_float((s << 16) | b));
+        V.P2[px] = make_float4(colour.x, colour.y, colour.z, __int_as_float(skip));
+        V.P3[px] = make_float4(light.x, light.y, light.z, 0.f);
       }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < kWfE; ++k) {
-      const uint32_t qi = (blockIdx.x - hit_blocks) * kWfChunk + (uint32_t)k * 256u + threadIdx.x;
-      if (qi < n_miss) {
-        const uint32_t px = V.q_miss[qi];
-        const float4 p0 = V.P0[px], p1 = V.P1[px], p2 = V.P2[px], p3 = V.P3[px];
-        f3 light = fma3v(environment<STRICT>(P, mk3(p1.x, p1.y, p1.z)), mk3(p2.x, p2.y, p2.z),
-                         mk3(p3.x, p3.y, p3.z));
-        path_end<STRICT>(P, V, O, frame, px, __float_as_uint(p0.w), __float_as_uint(p1.w) >> 16,
-                         light);
-      }
+    } else if (e >= first_miss) {
+      const uint32_t px = slice[e];
+      const float4 p0 = V.P0[px], p1 = V.P1[px], p2 = V.P2[px], p3 = V.P3[px];
+      f3 light = fma3v(environment<STRICT>(P, mk3(p1.x, p1.y, p1.z)), mk3(p2.x, p2.y, p2.z),
+                       mk3(p3.x, p3.y, p3.z));
+      path_end<STRICT>(P, V, O, frame, px, __float_as_uint(p0.w), __float_as_uint(p1.w) >> 16, light);
     }
   }
 }
 
-// Gathers the pixels that are still alive into the drain queue (q_hit, counts[16]).
+// Gathers the pixels that are still alive into the drain queue (q, counts[16]).
 __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels) {
   __shared__ uint32_t lds[kWfE * 4 + 1];
   const uint32_t first = blockIdx.x * kWfChunk;
@@ -224,7 +250,7 @@ __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels)
     pix[k] = first + (uint32_t)k * 256u + threadIdx.x;
     take[k] = pix[k] < n_pixels && V.alive[pix[k]] != 0;
   }
-  block_push(take, pix, V.q_hit, V.counts + 16, lds);
+  block_push(take, pix, V.q, V.counts + 16, lds);
 }
 
 // Finishes every pixel of the drain queue in registers: the loop of the regenerating
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
   uint32_t nrays = 0;
   if (qi < n) {
-    const uint32_t pix = V.q_hit[qi];
+    const uint32_t pix = V.q[qi];
     const float4 p0 = V.P0[pix], p1 = V.P1[pix], p2 = V.P2[pix], p3 = V.P3[pix], t = V.T[pix];
     const uint32_t px = pix % P.width, py = pix / P.width;
     const f3 base = pixel_direction(P, px, py);
@@ -325,10 +351,12 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
     WF_HIP(hipHostMalloc((void **)&impl->h_counts, 16 * sizeof(uint32_t)));
     for (auto &e : impl->ev) WF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  const size_t f4 = n * sizeof(float4), q = ((n * sizeof(uint32_t) + 255) / 256) * 256;
+  const size_t slices = (n + kWfChunk - 1) / kWfChunk;
+  const size_t f4 = n * sizeof(float4), q = slices * kWfChunk * sizeof(uint32_t);
+  const size_t sl = ((slices * sizeof(uint2) + 255) / 256) * 256;
   const size_t h = ((n * sizeof(float2) + 255) / 256) * 256;
   const size_t a = ((n + 255) / 256) * 256;
-  const size_t total = 5 * f4 + h + 2 * q + a + 256;
+  const size_t total = 5 * f4 + h + q + sl + a + 256;
   WF_HIP(hipMalloc((void **)&impl->slab, total));
   char *p = impl->slab;
   WfView &V = impl->view;
@@ -339,8 +367,8 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
   V.T = (float4 *)p; p += f4;
   V.H = (float2 *)p; p += h;
   V.alive = (unsigned char *)p; p += a;
-  V.q_hit = (uint32_t *)p; p += q;
-  V.q_miss = (uint32_t *)p; p += q;
+  V.q = (uint32_t *)p; p += q;
+  V.slice = (uint2 *)p; p += sl;
   V.counts = (uint32_t *)p;
   impl->n_pixels = n;
   return 0;
@@ -373,7 +401,7 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
     }
     hipLaunchKernelGGL((k_wf_extend<BVH, APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                        O.ids);
-    hipLaunchKernelGGL((k_wf_shade<STRICT, TEX>), dim3((bound + kWfChunk - 1u) / kWfChunk + 1u), dim3(256),
+    hipLaunchKernelGGL((k_wf_shade<STRICT, TEX>), dim3(window_blocks), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
     *launches += 2;
     if ((it + 1) % kCheckEvery == 0) {
