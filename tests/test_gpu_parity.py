@@ -761,3 +761,26 @@ def test_full_size_primary_ids_exact_without_jitter(oracle, size):
         got = gpu_render(ubo, sph, w, h, mode, 0)
         assert np.array_equal(got["ids"], want["ids"])
         assert got["rays"] == want["rays"] == w * h
+
+
+@pytest.mark.parametrize("accel", [rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH])
+def test_fast_policy_ids_exact_on_random_scenes(oracle, accel):
+    """Twelve random scenes of 150 overlapping spheres each (radii over three decades, some
+    enclosing the camera, some far away), jitter off: the fast policy's primary ids equal the
+    oracle's on every pixel, through the brute-force loop and through the LBVH."""
+    w, h = 160, 100
+    base = rt.default_scene()[0]
+    for seed in range(12):
+        rng = np.random.default_rng(1000 + seed)
+        n = 150
+        sph = np.repeat(base[None, :], n, axis=0).copy()
+        sph[:, 0] = rng.uniform(-12, 12, n)
+        sph[:, 1] = rng.uniform(-6, 6, n)
+        sph[:, 2] = rng.uniform(-40, 4, n)
+        sph[:, 3] = 10.0 ** rng.uniform(-1.5, 1.5, n)
+        sph = sph.astype(np.float32)
+        ubo = rt.make_ubo(w, h, 1, 1, diverge=0.0, yaw=float(rng.uniform(-0.5, 0.5)),
+                          pitch=float(rng.uniform(-0.3, 0.3)))
+        want = oracle.render(ubo, sph, w, h)
+        got = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, accel)
+        assert np.array_equal(got["ids"], want["ids"]), f"seed {seed}"
