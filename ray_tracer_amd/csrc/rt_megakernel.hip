@@ -208,19 +208,6 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
 // executes its own operations in the shader's order, and the closest hit does not depend on
 // visiting order (ties go to the lowest primitive id), so the results are those of
 // k_mega_nested bit for bit.
-#ifndef RT_SCHED_W_INNER
-#define RT_SCHED_W_INNER 2
-#endif
-#ifndef RT_SCHED_W_LEAF
-#define RT_SCHED_W_LEAF 5
-#endif
-#ifndef RT_SCHED_W_SHADE
-#define RT_SCHED_W_SHADE 2
-#endif
-#ifndef RT_SCHED_INNER_REPS
-#define RT_SCHED_INNER_REPS 4   // inner steps per scheduling decision (2: 5.24, 4: 5.08, 8: 5.26 ms)
-#endif
-
 // measurement builds only: -DRT_SCHED_STATS=<step> tallies, for that step, the lanes served
 // and the times it ran (x64) in the traversal counters
 #ifdef RT_SCHED_STATS
@@ -232,56 +219,6 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
 #else
 #define RT_SCHED_TALLY(step, n)
 #endif
-
-constexpr int kSearchOver = (int)kNullLeaf;  // never a real child reference
-
-template <bool APPROX>
-struct Search {
-  int node;  // >= 0 inner node, kSearchOver, otherwise ~leaf position
-  int sp;
-  float a;
-  f3 inv_d, oi;  // 1 / d and o / d
-  Closest<APPROX> best;
-};
-
-template <bool APPROX>
-__device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search<APPROX> &Q) {
-  Q.a = dot(d, d);
-  Q.best.reset(Q.a);
-  Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-  Q.oi = mk3(o.x * Q.inv_d.x, o.y * Q.inv_d.y, o.z * Q.inv_d.z);
-  for (uint32_t i = 0; i < S.n_large; ++i) Q.best.sphere(scene_f4(S.large_geom, i), (int)scene_u32(S.large_prim, i), o, d, Q.a);
-  Q.sp = 0;
-  if (S.n_spheres + S.n_tris == 1u) Q.node = S.n_large ? kSearchOver : ~0;
-  else Q.node = 0;
-}
-
-template <bool APPROX>
-__device__ __forceinline__ int search_pop(Search<APPROX> &Q, const int *stack) {
-  if (Q.sp == 0) return kSearchOver;
-  return stack[(--Q.sp) * kBlockThreads + threadIdx.x];
-}
-
-template <bool APPROX>
-__device__ __forceinline__ void search_inner_step(const Scene &S, Search<APPROX> &Q, int *stack) {
-  const BvhNode nd = load_node(S.nodes, Q.node);
-  const float best_dst = Q.best.dst();
-  const float limit = __builtin_fmaf(best_dst, 1.0e-4f, best_dst);
-  const float t0 = slab_entry(nd.lo0, nd.hi0, Q.oi, Q.inv_d, limit);
-  const float t1 = slab_entry(nd.lo1, nd.hi1, Q.oi, Q.inv_d, limit);
-  const int c0 = nd.child0, c1 = nd.child1;
-  const bool go0 = t0 < __builtin_inff() && c0 != (int)kNullLeaf;
-  const bool go1 = t1 < __builtin_inff() && c1 != (int)kNullLeaf;
-  if (go0 && go1) {
-    const bool first0 = t0 <= t1;
-    stack[(Q.sp++) * kBlockThreads + threadIdx.x] = first0 ? c1 : c0;
-    Q.node = first0 ? c0 : c1;
-  } else if (go0 || go1) {
-    Q.node = go0 ? c0 : c1;
-  } else {
-    Q.node = search_pop(Q, stack);
-  }
-}
 
 template <bool STRICT, bool TEX, bool APPROX>
 __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {

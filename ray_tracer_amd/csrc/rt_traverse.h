@@ -132,6 +132,78 @@ __device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stac
   else return closest_hit_brute<APPROX>(S, o, d, skip);
 }
 
+// ---- a search whose state outlives the loop iteration ----------------------------------
+// Kernels that let the WAVE choose, every iteration, which step to run for the lanes that
+// need it (k_mega_sched, and the scheduled extend and drain stages of the wavefront
+// pipeline) keep one Search per lane: current node, stack depth, best hit so far.  Steps:
+//   inner  fetch one node, test both child boxes, descend / push / pop
+//   leaf   test one primitive, pop
+// and a kernel-specific step for lanes whose search is over.  The step with the largest
+// weight x waiting lanes runs; a descending lane takes up to RT_SCHED_INNER_REPS inner steps
+// per decision.
+#ifndef RT_SCHED_W_INNER
+#define RT_SCHED_W_INNER 2
+#endif
+#ifndef RT_SCHED_W_LEAF
+#define RT_SCHED_W_LEAF 5
+#endif
+#ifndef RT_SCHED_W_SHADE
+#define RT_SCHED_W_SHADE 2
+#endif
+#ifndef RT_SCHED_INNER_REPS
+#define RT_SCHED_INNER_REPS 4   // inner steps per scheduling decision (2: 5.24, 4: 5.08, 8: 5.26 ms)
+#endif
+
+constexpr int kSearchOver = (int)kNullLeaf;  // never a real child reference
+
+template <bool APPROX>
+struct Search {
+  int node;  // >= 0 inner node, kSearchOver, otherwise ~leaf position
+  int sp;
+  float a;
+  f3 inv_d, oi;  // 1 / d and o / d
+  Closest<APPROX> best;
+};
+
+template <bool APPROX>
+__device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search<APPROX> &Q) {
+  Q.a = dot(d, d);
+  Q.best.reset(Q.a);
+  Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+  Q.oi = mk3(o.x * Q.inv_d.x, o.y * Q.inv_d.y, o.z * Q.inv_d.z);
+  for (uint32_t i = 0; i < S.n_large; ++i) Q.best.sphere(scene_f4(S.large_geom, i), (int)scene_u32(S.large_prim, i), o, d, Q.a);
+  Q.sp = 0;
+  if (S.n_spheres + S.n_tris == 1u) Q.node = S.n_large ? kSearchOver : ~0;
+  else Q.node = 0;
+}
+
+template <bool APPROX>
+__device__ __forceinline__ int search_pop(Search<APPROX> &Q, const int *stack) {
+  if (Q.sp == 0) return kSearchOver;
+  return stack[(--Q.sp) * kBlockThreads + threadIdx.x];
+}
+
+template <bool APPROX>
+__device__ __forceinline__ void search_inner_step(const Scene &S, Search<APPROX> &Q, int *stack) {
+  const BvhNode nd = load_node(S.nodes, Q.node);
+  const float best_dst = Q.best.dst();
+  const float limit = __builtin_fmaf(best_dst, 1.0e-4f, best_dst);
+  const float t0 = slab_entry(nd.lo0, nd.hi0, Q.oi, Q.inv_d, limit);
+  const float t1 = slab_entry(nd.lo1, nd.hi1, Q.oi, Q.inv_d, limit);
+  const int c0 = nd.child0, c1 = nd.child1;
+  const bool go0 = t0 < __builtin_inff() && c0 != (int)kNullLeaf;
+  const bool go1 = t1 < __builtin_inff() && c1 != (int)kNullLeaf;
+  if (go0 && go1) {
+    const bool first0 = t0 <= t1;
+    stack[(Q.sp++) * kBlockThreads + threadIdx.x] = first0 ? c1 : c0;
+    Q.node = first0 ? c0 : c1;
+  } else if (go0 || go1) {
+    Q.node = go0 ? c0 : c1;
+  } else {
+    Q.node = search_pop(Q, stack);
+  }
+}
+
 // LDS words a kernel must provide for the traversal stack (1 keeps the array legal)
 template <bool BVH>
 constexpr int bvh_stack_words() { return BVH ? kBvhStack * kBlockThreads : 1; }

@@ -163,6 +163,108 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
   }
 }
 
+// Extend through the LBVH.  The plain kernel above would run one whole tree search per lane
+// and entry, every lane waiting for the slowest search of its wave (14 % of the lanes busy
+// on the 10k-sphere scene).  Here the searches of a thread's kWfE entries are strung into one
+// wave-scheduled loop (see rt_traverse.h): inner and leaf steps as in k_mega_sched, and a
+// "next" step that stores the finished search and starts the thread's next live pixel.
+template <bool APPROX>
+__global__ __launch_bounds__(256) void k_wf_extend_tree(Scene S, WfView V, uint32_t slot,
+                                                        uint32_t n_pixels, int32_t *ids) {
+  __shared__ uint32_t lds[kWfE * 4 + 1];
+  __shared__ int stack[kBvhStack * kBlockThreads];
+  uint32_t *cnt = V.counts + 4u * (slot & 3u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t *z = V.counts + 4u * ((slot + 1u) & 3u);
+    z[1] = 0u;
+    z[2] = 0u;
+  }
+  const uint32_t first = blockIdx.x * kWfChunk;
+  uint32_t hit_mask = 0, miss_mask = 0;  // bit k: entry k of this thread hit / missed
+  int k = -1;                            // entry in flight; kWfE: none left
+  bool sample0 = false;
+  uint32_t pix = 0;
+  f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+  int skip = -1;
+  Search<APPROX> Q;
+  Q.node = kSearchOver;
+  Q.sp = 0;
+  Q.a = 1.f;
+  Q.inv_d = Q.oi = mk3(0.f, 0.f, 0.f);
+  Q.best.reset(1.f);
+
+  while (true) {
+    const bool busy = k >= 0 && k < kWfE;
+    const bool want_inner = busy && Q.node >= 0;
+    const bool want_next = k < kWfE && (!busy || Q.node == kSearchOver);
+    const bool want_leaf = busy && !want_inner && Q.node != kSearchOver;
+    const int n_inner = __builtin_popcountll(__ballot(want_inner));
+    const int n_leaf = __builtin_popcountll(__ballot(want_leaf));
+    const int n_next = __builtin_popcountll(__ballot(want_next));
+    if (n_inner + n_leaf + n_next == 0) break;
+    const int w_inner = n_inner * RT_SCHED_W_INNER, w_leaf = n_leaf * RT_SCHED_W_LEAF,
+              w_next = n_next * RT_SCHED_W_SHADE;
+    if (w_inner >= w_leaf && w_inner >= w_next) {
+      if (want_inner) {
+        search_inner_step(S, Q, stack);
+#pragma unroll
+        for (int rep = 1; rep < RT_SCHED_INNER_REPS; ++rep)
+          if (Q.node >= 0) search_inner_step(S, Q, stack);
+      }
+    } else if (w_leaf >= w_next) {
+      if (want_leaf) {
+        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        Q.node = search_pop(Q, stack);
+      }
+    } else if (want_next) {
+      if (busy) {  // the search of entry k is over: record it
+        const Hit h = Q.best.result();
+        V.H[pix] = make_float2(h.dst, __int_as_float(h.idx));
+        if (sample0) ids[pix] = h.idx;
+        if (h.idx >= 0) hit_mask |= 1u << k;
+        else miss_mask |= 1u << k;
+      }
+      // the thread's next live pixel, if any
+      for (++k; k < kWfE; ++k) {
+        pix = first + (uint32_t)k * 256u + threadIdx.x;
+        if (pix < n_pixels && V.alive[pix]) break;
+      }
+      if (k < kWfE) {
+        const float4 p0 = V.P0[pix], p1 = V.P1[pix];
+        skip = S.n_tris ? __float_as_int(V.P2[pix].w) : -1;
+        sample0 = __float_as_uint(p1.w) == 0u;  // sample 0, bounce 0
+        o = mk3(p0.x, p0.y, p0.z);
+        d = mk3(p1.x, p1.y, p1.z);
+        search_begin(S, o, d, Q);
+      }
+    }
+  }
+
+  bool is_hit[kWfE], is_miss[kWfE];
+  uint32_t pixk[kWfE];
+#pragma unroll
+  for (int j = 0; j < kWfE; ++j) {
+    is_hit[j] = (hit_mask >> j) & 1u;
+    is_miss[j] = (miss_mask >> j) & 1u;
+    pixk[j] = first + (uint32_t)j * 256u + threadIdx.x;
+  }
+  uint32_t off[kWfE];
+  uint32_t *slice = V.q + first;
+  const uint32_t n_hit = block_rank(is_hit, off, lds);
+#pragma unroll
+  for (int j = 0; j < kWfE; ++j)
+    if (is_hit[j]) slice[off[j]] = pixk[j];
+  const uint32_t n_miss = block_rank(is_miss, off, lds);
+#pragma unroll
+  for (int j = 0; j < kWfE; ++j)
+    if (is_miss[j]) slice[kWfChunk - n_miss + off[j]] = pixk[j];
+  if (threadIdx.x == 0) {
+    V.slice[blockIdx.x] = make_uint2(n_hit, n_miss);
+    if (n_hit) atomicAdd(cnt + 1, n_hit);
+    if (n_miss) atomicAdd(cnt + 2, n_miss);
+  }
+}
+
 // A path ended with radiance `light`: fold it into the pixel's sample sum and either
 // start the next sample (returns true, state written) or finish the pixel's frame.
 template <bool STRICT>
@@ -310,6 +412,103 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
   if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
 }
 
+// The drain launch for LBVH scenes: the same resumption, in k_mega_sched's wave-scheduled
+// form (inner / leaf / shade steps chosen by waiting-lane count).
+template <bool STRICT, bool TEX, bool APPROX>
+__global__ __launch_bounds__(256) void k_wf_drain_tree(Params P, Scene S, WfView V, uint32_t frame,
+                                                       Outputs O) {
+  __shared__ int stack[kBvhStack * kBlockThreads];
+  const uint32_t n = V.counts[16];
+  const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
+  uint32_t nrays = 0;
+  bool active = qi < n;
+  const uint32_t pix = active ? V.q[qi] : 0u;
+  const uint32_t px = pix % P.width, py = pix / P.width;
+  const f3 base = pixel_direction(P, px, py);
+  uint32_t rng = 0;
+  int s = 0, b = 0, skip = -1, id0 = -2;
+  f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+  f3 colour = mk3(1.f, 1.f, 1.f), light = mk3(0.f, 0.f, 0.f), total = mk3(0.f, 0.f, 0.f);
+  if (active) {
+    const float4 p0 = V.P0[pix], p1 = V.P1[pix], p2 = V.P2[pix], p3 = V.P3[pix], t = V.T[pix];
+    rng = __float_as_uint(p0.w);
+    const uint32_t sb = __float_as_uint(p1.w);
+    s = (int)(sb >> 16);
+    b = (int)(sb & 0xffffu);
+    o = mk3(p0.x, p0.y, p0.z);
+    d = mk3(p1.x, p1.y, p1.z);
+    colour = mk3(p2.x, p2.y, p2.z);
+    light = mk3(p3.x, p3.y, p3.z);
+    total = mk3(t.x, t.y, t.z);
+    skip = __float_as_int(p2.w);
+  }
+  Search<APPROX> Q;
+  search_begin(S, o, d, Q);
+
+  while (true) {
+    const bool want_inner = active && Q.node >= 0;
+    const bool want_shade = active && Q.node == kSearchOver;
+    const bool want_leaf = active && !want_inner && !want_shade;
+    const int n_inner = __builtin_popcountll(__ballot(want_inner));
+    const int n_leaf = __builtin_popcountll(__ballot(want_leaf));
+    const int n_shade = __builtin_popcountll(__ballot(want_shade));
+    if (n_inner + n_leaf + n_shade == 0) break;
+    const int w_inner = n_inner * RT_SCHED_W_INNER, w_leaf = n_leaf * RT_SCHED_W_LEAF,
+              w_shade = n_shade * RT_SCHED_W_SHADE;
+    if (w_inner >= w_leaf && w_inner >= w_shade) {
+      if (want_inner) {
+        search_inner_step(S, Q, stack);
+#pragma unroll
+        for (int rep = 1; rep < RT_SCHED_INNER_REPS; ++rep)
+          if (Q.node >= 0) search_inner_step(S, Q, stack);
+      }
+    } else if (w_leaf >= w_shade) {
+      if (want_leaf) {
+        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        Q.node = search_pop(Q, stack);
+      }
+    } else if (want_shade) {
+      const Hit h = Q.best.result();
+      ++nrays;
+      if (s == 0 && b == 0) id0 = h.idx;
+      bool path_done;
+      if (h.idx >= 0) {
+        skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+        ++b;
+        path_done = b >= P.n_bounce;
+      } else {
+        light = fma3v(environment<STRICT>(P, d), colour, light);
+        path_done = true;
+      }
+      if (path_done) {
+        total = total + light;
+        ++s;
+        if (s >= P.n_spp) {
+          active = false;
+        } else {
+          sample_ray<STRICT>(P, base, rng, o, d);
+          light = mk3(0.f, 0.f, 0.f);
+          colour = mk3(1.f, 1.f, 1.f);
+          b = 0;
+          skip = -1;
+        }
+      }
+      if (active) {
+        search_begin(S, o, d, Q);
+      } else {
+        float4 acc = O.accum[pix];
+        uchar4 img = O.rgba8[pix];
+        frame_epilogue(P, total, (float)frame, O.linear_accum, acc, img);
+        O.accum[pix] = acc;
+        O.rgba8[pix] = img;
+        if (id0 != -2) O.ids[pix] = id0;
+      }
+    }
+  }
+  const uint32_t wsum = wave_sum_u32(nrays);
+  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+}
+
 // ---- host side ---------------------------------------------------------------------
 struct WavefrontState::Impl {
   size_t n_pixels = 0;
@@ -394,13 +593,21 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
     const uint32_t slot = (uint32_t)(it & 3u);
     if (bound <= drain_threshold) {
       hipLaunchKernelGGL(k_wf_compact, dim3(window_blocks), dim3(256), 0, stream, V, n);
-      hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0, stream,
-                         P, S, V, frame, O);
+      if constexpr (BVH)
+        hipLaunchKernelGGL((k_wf_drain_tree<STRICT, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0,
+                           stream, P, S, V, frame, O);
+      else
+        hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0,
+                           stream, P, S, V, frame, O);
       *launches += 2;
       break;
     }
-    hipLaunchKernelGGL((k_wf_extend<BVH, APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
-                       O.ids);
+    if constexpr (BVH)
+      hipLaunchKernelGGL((k_wf_extend_tree<APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+                         O.ids);
+    else
+      hipLaunchKernelGGL((k_wf_extend<BVH, APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+                         O.ids);
     hipLaunchKernelGGL((k_wf_shade<STRICT, TEX>), dim3(window_blocks), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
     *launches += 2;
