@@ -49,19 +49,25 @@ struct WfView {
   uint32_t *counts;  // [4 slots][4]: -, hits, misses, - (totals); [16]: length of the drain queue
 };
 
-constexpr int kWfE = 8;                    // queue entries per thread
-constexpr uint32_t kWfChunk = 256u * kWfE;  // queue entries per block
+// Queue entries per thread of the extend and shade stages (a block handles 256 x E pixels,
+// and that is the size of its queue slice).  Brute-force scenes want few, long blocks (8:
+// 8.7 ms per frame against 9.7 with 4 and 11.5 with 2 on the 3-sphere scene); a tree search
+// is long and ragged, so LBVH scenes want many waves instead (2: 4.6 ms against 4.9 with 4
+// and 6.0 with 8 on the 10k-sphere scene).
+constexpr int kWfEBrute = 8, kWfETree = 2;
+constexpr int kWfE = kWfEBrute;             // k_wf_compact's own chunking
+constexpr uint32_t kWfChunk = 256u * kWfE;
 
 // Ranks the entries (lane, k) with take[k] set in (k, wave, lane) order: off[k] is the
 // position of this thread's k-th entry among them, the return value their number.
 // Ballots rank the lanes of each wave, a scan over the kWfE x 4 (k, wave) groups in LDS
 // ranks those.  Must be reached by every thread of the block; lds holds kWfE * 4 + 1 words.
-__device__ __forceinline__ uint32_t block_rank(const bool (&take)[kWfE], uint32_t (&off)[kWfE],
-                                               uint32_t *lds) {
+template <int E>
+__device__ __forceinline__ uint32_t block_rank(const bool (&take)[E], uint32_t (&off)[E], uint32_t *lds) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t rank[kWfE];
+  uint32_t rank[E];
 #pragma unroll
-  for (int k = 0; k < kWfE; ++k) {
+  for (int k = 0; k < E; ++k) {
     const unsigned long long m = __ballot(take[k]);
     rank[k] = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) lds[k * 4 + wave] = (uint32_t)__popcll(m);
@@ -70,33 +76,34 @@ __device__ __forceinline__ uint32_t block_rank(const bool (&take)[kWfE], uint32_
   if (threadIdx.x == 0) {
     uint32_t run = 0;
 #pragma unroll
-    for (int j = 0; j < kWfE * 4; ++j) {
+    for (int j = 0; j < E * 4; ++j) {
       const uint32_t c = lds[j];
       lds[j] = run;
       run += c;
     }
-    lds[kWfE * 4] = run;
+    lds[E * 4] = run;
   }
   __syncthreads();
-  const uint32_t total = lds[kWfE * 4];
+  const uint32_t total = lds[E * 4];
 #pragma unroll
-  for (int k = 0; k < kWfE; ++k) off[k] = lds[k * 4 + wave] + rank[k];
+  for (int k = 0; k < E; ++k) off[k] = lds[k * 4 + wave] + rank[k];
   __syncthreads();
   return total;
 }
 
 // Appends v[k] to the global queue q for every entry with take[k] set: block_rank plus ONE
 // returning atomic per block for the output range (used once per frame, by k_wf_compact).
-__device__ __forceinline__ void block_push(const bool (&take)[kWfE], const uint32_t (&v)[kWfE],
-                                           uint32_t *q, uint32_t *count, uint32_t *lds) {
+template <int E>
+__device__ __forceinline__ void block_push(const bool (&take)[E], const uint32_t (&v)[E], uint32_t *q,
+                                           uint32_t *count, uint32_t *lds) {
   __shared__ uint32_t base_slot;
-  uint32_t off[kWfE];
+  uint32_t off[E];
   const uint32_t total = block_rank(take, off, lds);
   if (threadIdx.x == 0) base_slot = total ? atomicAdd(count, total) : 0u;
   __syncthreads();
   const uint32_t base = base_slot;
 #pragma unroll
-  for (int k = 0; k < kWfE; ++k)
+  for (int k = 0; k < E; ++k)
     if (take[k]) q[base + off[k]] = v[k];
 }
 
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void k_wf_init(Params P, uint32_t frame, WfVie
 template <bool BVH, bool APPROX>
 __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t slot, uint32_t n_pixels,
                                                    int32_t *ids) {
-  __shared__ uint32_t lds[kWfE * 4 + 1];
+  __shared__ uint32_t lds[kWfEBrute * 4 + 1];
   __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t *cnt = V.counts + 4u * (slot & 3u);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -128,11 +135,11 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
     z[1] = 0u;
     z[2] = 0u;
   }
-  const uint32_t first = blockIdx.x * kWfChunk;
-  bool is_hit[kWfE], is_miss[kWfE];
-  uint32_t pix[kWfE];
+  const uint32_t first = blockIdx.x * (256u * kWfEBrute);
+  bool is_hit[kWfEBrute], is_miss[kWfEBrute];
+  uint32_t pix[kWfEBrute];
 #pragma unroll
-  for (int k = 0; k < kWfE; ++k) {
+  for (int k = 0; k < kWfEBrute; ++k) {
     pix[k] = first + (uint32_t)k * 256u + threadIdx.x;
     is_hit[k] = is_miss[k] = false;
     if (pix[k] < n_pixels && V.alive[pix[k]]) {
@@ -146,16 +153,16 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
     }
   }
   // this block's slice of the queue: hits from the front, misses from the back
-  uint32_t off[kWfE];
+  uint32_t off[kWfEBrute];
   uint32_t *slice = V.q + first;
   const uint32_t n_hit = block_rank(is_hit, off, lds);
 #pragma unroll
-  for (int k = 0; k < kWfE; ++k)
+  for (int k = 0; k < kWfEBrute; ++k)
     if (is_hit[k]) slice[off[k]] = pix[k];
   const uint32_t n_miss = block_rank(is_miss, off, lds);
 #pragma unroll
-  for (int k = 0; k < kWfE; ++k)
-    if (is_miss[k]) slice[kWfChunk - n_miss + off[k]] = pix[k];
+  for (int k = 0; k < kWfEBrute; ++k)
+    if (is_miss[k]) slice[(256u * kWfEBrute) - n_miss + off[k]] = pix[k];
   if (threadIdx.x == 0) {
     V.slice[blockIdx.x] = make_uint2(n_hit, n_miss);
     if (n_hit) atomicAdd(cnt + 1, n_hit);    // totals for the host; nobody waits on them
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
 template <bool APPROX>
 __global__ __launch_bounds__(256) void k_wf_extend_tree(Scene S, WfView V, uint32_t slot,
                                                         uint32_t n_pixels, int32_t *ids) {
-  __shared__ uint32_t lds[kWfE * 4 + 1];
+  __shared__ uint32_t lds[kWfETree * 4 + 1];
   __shared__ int stack[kBvhStack * kBlockThreads];
   uint32_t *cnt = V.counts + 4u * (slot & 3u);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(256) void k_wf_extend_tree(Scene S, WfView V, uint3
     z[1] = 0u;
     z[2] = 0u;
   }
-  const uint32_t first = blockIdx.x * kWfChunk;
+  const uint32_t first = blockIdx.x * (256u * kWfETree);
   uint32_t hit_mask = 0, miss_mask = 0;  // bit k: entry k of this thread hit / missed
-  int k = -1;                            // entry in flight; kWfE: none left
+  int k = -1;                            // entry in flight; kWfETree: none left
   bool sample0 = false;
   uint32_t pix = 0;
   f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
@@ -194,9 +201,9 @@ __global__ __launch_bounds__(256) void k_wf_extend_tree(Scene S, WfView V, uint3
   Q.best.reset(1.f);
 
   while (true) {
-    const bool busy = k >= 0 && k < kWfE;
+    const bool busy = k >= 0 && k < kWfETree;
     const bool want_inner = busy && Q.node >= 0;
-    const bool want_next = k < kWfE && (!busy || Q.node == kSearchOver);
+    const bool want_next = k < kWfETree && (!busy || Q.node == kSearchOver);
     const bool want_leaf = busy && !want_inner && Q.node != kSearchOver;
     const int n_inner = __builtin_popcountll(__ballot(want_inner));
     const int n_leaf = __builtin_popcountll(__ballot(want_leaf));
@@ -225,11 +232,11 @@ __global__ __launch_bounds__(256) void k_wf_extend_tree(Scene S, WfView V, uint3
         else miss_mask |= 1u << k;
       }
       // the thread's next live pixel, if any
-      for (++k; k < kWfE; ++k) {
+      for (++k; k < kWfETree; ++k) {
         pix = first + (uint32_t)k * 256u + threadIdx.x;
         if (pix < n_pixels && V.alive[pix]) break;
       }
-      if (k < kWfE) {
+      if (k < kWfETree) {
         const float4 p0 = V.P0[pix], p1 = V.P1[pix];
         skip = S.n_tris ? __float_as_int(V.P2[pix].w) : -1;
         sample0 = __float_as_uint(p1.w) == 0u;  // sample 0, bounce 0
@@ -240,24 +247,24 @@ __global__ __launch_bounds__(256) void k_wf_extend_tree(Scene S, WfView V, uint3
     }
   }
 
-  bool is_hit[kWfE], is_miss[kWfE];
-  uint32_t pixk[kWfE];
+  bool is_hit[kWfETree], is_miss[kWfETree];
+  uint32_t pixk[kWfETree];
 #pragma unroll
-  for (int j = 0; j < kWfE; ++j) {
+  for (int j = 0; j < kWfETree; ++j) {
     is_hit[j] = (hit_mask >> j) & 1u;
     is_miss[j] = (miss_mask >> j) & 1u;
     pixk[j] = first + (uint32_t)j * 256u + threadIdx.x;
   }
-  uint32_t off[kWfE];
+  uint32_t off[kWfETree];
   uint32_t *slice = V.q + first;
   const uint32_t n_hit = block_rank(is_hit, off, lds);
 #pragma unroll
-  for (int j = 0; j < kWfE; ++j)
+  for (int j = 0; j < kWfETree; ++j)
     if (is_hit[j]) slice[off[j]] = pixk[j];
   const uint32_t n_miss = block_rank(is_miss, off, lds);
 #pragma unroll
-  for (int j = 0; j < kWfE; ++j)
-    if (is_miss[j]) slice[kWfChunk - n_miss + off[j]] = pixk[j];
+  for (int j = 0; j < kWfETree; ++j)
+    if (is_miss[j]) slice[(256u * kWfETree) - n_miss + off[j]] = pixk[j];
   if (threadIdx.x == 0) {
     V.slice[blockIdx.x] = make_uint2(n_hit, n_miss);
     if (n_hit) atomicAdd(cnt + 1, n_hit);
@@ -294,7 +301,7 @@ __device__ __forceinline__ bool path_end(const Params &P, const WfView &V, const
   return true;
 }
 
-template <bool STRICT, bool TEX>
+template <bool STRICT, bool TEX, int E>
 __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, uint32_t slot,
                                                   uint32_t frame, Outputs O) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -303,10 +310,10 @@ __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, u
     if (traced) atomicAdd(O.rays, (unsigned long long)traced);
   }
   const uint2 fill = V.slice[blockIdx.x];
-  const uint32_t n_hit = fill.x, first_miss = kWfChunk - fill.y;
-  const uint32_t *slice = V.q + blockIdx.x * kWfChunk;
+  const uint32_t n_hit = fill.x, first_miss = (256u * E) - fill.y;
+  const uint32_t *slice = V.q + blockIdx.x * (256u * E);
 #pragma unroll 2
-  for (int k = 0; k < kWfE; ++k) {
+  for (int k = 0; k < E; ++k) {
     const uint32_t e = (uint32_t)k * 256u + threadIdx.x;
     if (e < n_hit) {
       const uint32_t px = slice[e];
@@ -550,8 +557,8 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
     WF_HIP(hipHostMalloc((void **)&impl->h_counts, 16 * sizeof(uint32_t)));
     for (auto &e : impl->ev) WF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  const size_t slices = (n + kWfChunk - 1) / kWfChunk;
-  const size_t f4 = n * sizeof(float4), q = slices * kWfChunk * sizeof(uint32_t);
+  const size_t slices = (n + 256 * kWfETree - 1) / (256 * kWfETree);  // the finer slicing
+  const size_t f4 = n * sizeof(float4), q = (n + 256 * kWfEBrute) * sizeof(uint32_t);
   const size_t sl = ((slices * sizeof(uint2) + 255) / 256) * 256;
   const size_t h = ((n * sizeof(float2) + 255) / 256) * 256;
   const size_t a = ((n + 255) / 256) * 256;
@@ -580,7 +587,9 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
   const WfView &V = impl->view;
   const uint32_t n = (uint32_t)impl->n_pixels;
   const uint32_t full_blocks = (n + 255u) / 256u;
-  const uint32_t window_blocks = (n + kWfChunk - 1u) / kWfChunk;
+  constexpr int E = BVH ? kWfETree : kWfEBrute;
+  const uint32_t window_blocks = (n + 256u * E - 1u) / (256u * E);
+  const uint32_t compact_blocks = (n + kWfChunk - 1u) / kWfChunk;
   WF_HIP(hipMemsetAsync(V.counts, 0, 128, stream));
   hipLaunchKernelGGL((k_wf_init<STRICT>), dim3(full_blocks), dim3(256), 0, stream, P, frame, V);
   ++*launches;
@@ -592,7 +601,7 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
   for (uint64_t it = 0; it < max_iters; ++it) {
     const uint32_t slot = (uint32_t)(it & 3u);
     if (bound <= drain_threshold) {
-      hipLaunchKernelGGL(k_wf_compact, dim3(window_blocks), dim3(256), 0, stream, V, n);
+      hipLaunchKernelGGL(k_wf_compact, dim3(compact_blocks), dim3(256), 0, stream, V, n);
       if constexpr (BVH)
         hipLaunchKernelGGL((k_wf_drain_tree<STRICT, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0,
                            stream, P, S, V, frame, O);
@@ -608,7 +617,7 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
     else
       hipLaunchKernelGGL((k_wf_extend<BVH, APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                          O.ids);
-    hipLaunchKernelGGL((k_wf_shade<STRICT, TEX>), dim3(window_blocks), dim3(256),
+    hipLaunchKernelGGL((k_wf_shade<STRICT, TEX, E>), dim3(window_blocks), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
     *launches += 2;
     if ((it + 1) % kCheckEvery == 0) {
