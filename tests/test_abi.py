@@ -150,3 +150,16 @@ def test_write_png_round_trips(tmp_path):
     raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(37, 1 + 300 * 3)
     assert (raw[:, 0] == 0).all()
     assert np.array_equal(raw[:, 1:].reshape(37, 300, 3), img[::-1, :, :3])
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """include/*.h compiled as strict C99 together with the call sequence a C host makes."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-c",
+                          os.path.join(root, "tests", "native", "abi_c99.c"), "-o", str(tmp_path / "abi.o")],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
