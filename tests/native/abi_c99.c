@@ -1,6 +1,6 @@
 /* The public headers must be plain C: this file is compiled (not run) by
  * tests/test_abi.py with gcc -std=c99 -pedantic -Wall -Werror.  It also spells out the
- * calls a C host makes, in the order INTEGRATION.md gives them. */
+ * calls a C host makes: create, scene, parameters, render, read back, destroy. */
 #include <stddef.h>
 #include <string.h>
 
