@@ -784,3 +784,31 @@ def test_fast_policy_ids_exact_on_random_scenes(oracle, accel):
         want = oracle.render(ubo, sph, w, h)
         got = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, accel)
         assert np.array_equal(got["ids"], want["ids"]), f"seed {seed}"
+
+
+def test_batched_and_plain_regen_loops_are_bit_identical():
+    """k_mega_regen has a throughput form (path ends gathered per wave) chosen by tile count.
+    The choice is read once per process (RT_REGEN_BATCH_TILES), so two child processes render
+    the same frames with either loop forced; images, ids and ray counts must be identical."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import hashlib, sys\n"
+        "import ray_tracer_amd as rt\n"
+        "w, h = 328, 200\n"
+        "with rt.Renderer(w, h) as r:\n"
+        "    r.set_params(rt.make_ubo(w, h, 6, 12, sun_intensity=2.0)); r.set_spheres(rt.default_scene())\n"
+        "    r.render(0, 3, 1); r.sync()\n"
+        "    m = hashlib.sha256()\n"
+        "    m.update(r.read_accum().tobytes()); m.update(r.read_rgba8().tobytes()); m.update(r.read_primary_ids().tobytes())\n"
+        "    print('DIGEST', m.hexdigest(), r.stats().rays)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for tiles in ("0", "4000000000"):
+        env = dict(os.environ, RT_REGEN_BATCH_TILES=tiles, PYTHONPATH=root)
+        res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0, res.stderr
+        out.append([l for l in res.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert out[0] == out[1]
