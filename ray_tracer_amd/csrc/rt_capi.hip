@@ -362,8 +362,10 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
   c->d_geom = nullptr;
   if (c->d_material) RT_HIP(hipFree(c->d_material));
   c->d_material = nullptr;
-  const size_t alloc_n = count ? count : 1;
+  // the brute-force search fetches geometry four records at a time: pad, and clear the padding
+  const size_t alloc_n = ((size_t)count + 3u) / 4u * 4u + 4u;
   RT_HIP(hipMalloc(&c->d_geom, alloc_n * sizeof(float4)));
+  RT_HIP(hipMemset(c->d_geom, 0, alloc_n * sizeof(float4)));
   RT_HIP(hipMalloc(&c->d_material, ((size_t)count + 1) * 3 * sizeof(float4)));  // + the mesh's
   RT_HIP(hipMemcpy(c->d_material + 3 * (size_t)count, c->mesh_material, sizeof c->mesh_material,
                    hipMemcpyHostToDevice));
@@ -461,7 +463,8 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
   c->order_interval = 1;
   c->launches_since_order = 0;
   if (!c->d_material) {  // no spheres uploaded yet: an empty sphere set
-    RT_HIP(hipMalloc(&c->d_geom, sizeof(float4)));
+    RT_HIP(hipMalloc(&c->d_geom, 4 * sizeof(float4)));
+    RT_HIP(hipMemset(c->d_geom, 0, 4 * sizeof(float4)));
     RT_HIP(hipMalloc(&c->d_material, 3 * sizeof(float4)));
     c->n_spheres = 0;
   }
@@ -662,12 +665,12 @@ int rt_debug_eval(int device, int op, const float *a, const float *b, float *out
   if (n == 0) return RT_OK;
   RT_HIP(hipSetDevice(device));
   float *da = nullptr, *db = nullptr, *dout = nullptr;
-  RT_HIP(hipMalloc(&da, n * sizeof(float)));
-  RT_HIP(hipMalloc(&dout, n * sizeof(float)));
-  if (b) RT_HIP(hipMalloc(&db, n * sizeof(float)));
-  RT_HIP(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
-  if (b) RT_HIP(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
-  hipError_t e = rt::launch_debug_eval(op, da, db, dout, n, nullptr);
+  hipError_t e = hipMalloc(&da, n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&dout, n * sizeof(float));
+  if (e == hipSuccess && b) e = hipMalloc(&db, n * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && b) e = hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = rt::launch_debug_eval(op, da, db, dout, n, nullptr);
   if (e == hipSuccess) e = hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost);
   hipFree(da);
   hipFree(dout);

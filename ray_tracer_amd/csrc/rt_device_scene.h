@@ -94,6 +94,7 @@ struct Outputs {
   const uint32_t *tile_order;
   uint32_t *tile_cost;
   uint32_t tiles_x, n_tiles;
+  uint32_t chain_ranks;     // k_mega_regen, mixed form: blocks below this rank run the plain loop
 };
 
 }  // namespace rt

@@ -20,6 +20,12 @@
 #ifndef RT_REGEN_END_BATCH
 #define RT_REGEN_END_BATCH 8   // ended paths a wave gathers before it runs the path-end code
 #endif
+#ifndef RT_REGEN_MIXED_WAVES
+#define RT_REGEN_MIXED_WAVES 1
+#endif
+#ifndef RT_REGEN_CHAIN_DIV
+#define RT_REGEN_CHAIN_DIV 32u  // a mixed launch runs its first n_tiles / 32 blocks through the plain loop (8..128 within 2 %)
+#endif
 #ifndef RT_REGEN_BATCH_TILES
 #define RT_REGEN_BATCH_TILES 12288u  // launches with at least this many tiles (8 x what the device holds) use the batched loop
 #endif
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
           ++nrays;
           if (s == 0 && b == 0) id0 = h.idx;
           if (h.idx >= 0) {
-            skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+            skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
           } else {
             light = fma3v(environment<STRICT>(P, d), colour, light);
             break;
@@ -111,9 +117,19 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
 }
 
 // Requires n_spp >= 1 and n_bounce >= 1 (the host routes other cases to k_mega_nested).
-template <bool STRICT, bool BVH, bool TEX, bool APPROX, bool BATCHED>
-__global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+// FORM: which of the two loops below the blocks run: kRegenPlain, kRegenBatched, or
+// kRegenMixed = the plain loop for the first O.chain_ranks blocks of an ordered launch (the
+// tiles with the longest chains, which set the launch time) and the batched loop for the rest
+// (whose job is throughput).
+constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
+template <bool STRICT, bool BVH, bool TEX, bool APPROX, int FORM>
+__global__ __launch_bounds__(256, FORM == kRegenMixed ? RT_REGEN_MIXED_WAVES : RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
+  // The plain loop is used where one wave's chain of segments sets the launch time: its
+  // brute-force search is the form tuned for a wave running alone, and the hit carries the
+  // sphere's centre to the shading code instead of having it fetched again.
+  constexpr bool CHAIN = !BVH;
+  const bool batched = FORM == kRegenMixed ? blockIdx.x >= O.chain_ranks : FORM == kRegenBatched;
   const uint32_t tile = ordered_tile(O);
   uint32_t px, py;
   pixel_of_tile(tile, O.tiles_x, px, py);
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
     f3 light = mk3(0.f, 0.f, 0.f), colour = mk3(1.f, 1.f, 1.f);
     int skip = -1;
 
-    if constexpr (BATCHED) {
+    if (batched) {
       // Throughput form, for launches with many more tiles than the device holds at once.
       // A path that ended (missed everything, or reached the bounce limit) waits until
       // RT_REGEN_END_BATCH lanes of the wave have one to end, or until no lane can trace;
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
           ++nrays;
           if (s == 0 && b == 0) id0 = h.idx;
           if (h.idx >= 0) {
-            skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+            skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
             ++b;
             if (b >= P.n_bounce) ended = 2;
           } else {
@@ -195,12 +211,12 @@ __global__ __launch_bounds__(256, RT_MEGA_WAVES) void k_mega_regen(Params P, Sce
     } else {
       bool active = true;
       while (active) {
-        Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
+        Hit h = closest_hit<BVH, APPROX, CHAIN>(S, o, d, stack, skip);
         ++nrays;
         if (s == 0 && b == 0) id0 = h.idx;
         bool path_done;
         if (h.idx >= 0) {
-          skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+          skip = shade_hit<STRICT, TEX, APPROX, CHAIN>(S, h, rng, o, d, light, colour);
           ++b;
           path_done = b >= P.n_bounce;
         } else {
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -394,6 +410,13 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
                                 const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
   dim3 tiles(O.n_tiles, 1, 1);  // k_mega_regen and k_mega_sched take tiles from a 1-D grid
+#ifdef RT_DEBUG_TILE_LIMIT
+  // measurement build (tools/lone_tile.py): only the first N tiles of the order are launched
+  if (const char *e = std::getenv("RT_DEBUG_TILE_LIMIT")) {
+    const unsigned long v = std::strtoul(e, nullptr, 10);
+    if (v && v < O.n_tiles) tiles.x = (uint32_t)v;
+  }
+#endif
   dim3 block(256, 1, 1);
   // k_mega_regen and k_mega_sched need at least one sample and one bounce
   static const bool sched = [] {
@@ -404,14 +427,39 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     const char *e = getenv("RT_REGEN_BATCH_TILES");
     return e ? (uint32_t)strtoul(e, nullptr, 10) : RT_REGEN_BATCH_TILES;
   }();
+  static const uint32_t chain_div = [] {
+    const char *e = getenv("RT_REGEN_CHAIN_DIV");
+    const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 10) : RT_REGEN_CHAIN_DIV;
+    return v ? v : 1u;
+  }();
+  static const int forced_form = [] {  // RT_REGEN_FORM=plain|batched|mixed pins the loop (tests, measurements)
+    const char *e = getenv("RT_REGEN_FORM");
+    if (!e) return -1;
+    return e[0] == 'p' ? kRegenPlain : e[0] == 'b' ? kRegenBatched : e[0] == 'm' ? kRegenMixed : -1;
+  }();
   if (nested)
     hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX, APPROX>), grid, block, 0, stream, P, S, F, O);
   else if (BVH && sched)
     hipLaunchKernelGGL((k_mega_sched<STRICT, TEX, APPROX>), tiles, block, 0, stream, P, S, F, O);
-  else if (!BVH && O.n_tiles >= batch_tiles)
-    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, !BVH>), tiles, block, 0, stream, P, S, F, O);
-  else
-    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, false>), tiles, block, 0, stream, P, S, F, O);
+  else if (BVH)
+    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, O);
+  else {
+    // Brute-force scenes.  Many tiles: throughput is everything, the batched loop.  Fewer: the
+    // longest chain sets the time; with a measured order its tiles (and only they) get the
+    // plain loop, without one every tile does.  1920x1080: plain 1.40, batched 1.39, mixed
+    // 1.27 ms; 3840x2160: 5.07, 4.48, 4.60 (the mixed kernel holds both loops' registers).
+    int form = O.n_tiles >= batch_tiles ? kRegenBatched : (O.tile_order ? kRegenMixed : kRegenPlain);
+    if (forced_form >= 0 && (forced_form != kRegenMixed || O.tile_order)) form = forced_form;
+    Outputs Q = O;
+    Q.chain_ranks = (O.n_tiles + chain_div - 1u) / chain_div;
+    constexpr bool B = !BVH;  // keeps the BVH instantiations of the brute-force forms out of the library
+    if (form == kRegenMixed)
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenMixed : kRegenPlain>), tiles, block, 0, stream, P, S, F, Q);
+    else if (form == kRegenBatched)
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenBatched : kRegenPlain>), tiles, block, 0, stream, P, S, F, Q);
+    else
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, Q);
+  }
   return hipGetLastError();
 }
 

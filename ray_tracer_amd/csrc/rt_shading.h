@@ -82,6 +82,9 @@ __device__ __forceinline__ void sample_ray(const Params &P, f3 base_dir, uint32_
 struct Hit {
   float dst;
   int idx;  // -1: miss
+  // centre of the sphere that was hit, for callers that shade in the same kernel (it saves
+  // them a dependent fetch); dead code everywhere else
+  float cx, cy, cz;
 };
 
 // float4 in the constant address space (memory no kernel of the launch writes)
@@ -154,6 +157,9 @@ __device__ __forceinline__ void sphere_candidate_tie(float4 g, int idx, f3 o, f3
       if (q >= 0.0f && (q < best.dst || (q == best.dst && idx < best.idx))) {
         best.dst = q;
         best.idx = idx;
+        best.cx = g.x;
+        best.cy = g.y;
+        best.cz = g.z;
         best_n = n;
       }
     }
@@ -185,6 +191,7 @@ struct Closest<false> {
   __device__ __forceinline__ void reset(float) {
     best.dst = 3.402823466e+38f;
     best.idx = kNoHit;
+    best.cx = best.cy = best.cz = 0.0f;
     best_n = __builtin_inff();
   }
   __device__ __forceinline__ void sphere(float4 g, int idx, f3 o, f3 d, float a) {
@@ -208,7 +215,9 @@ struct Closest<true> {
   float bh, disc;  // its inputs, for an exact re-evaluation
   float rcp_a;
   int idx;
+  float cx, cy, cz;  // its centre (see Hit)
   __device__ __forceinline__ void reset(float a) {
+    cx = cy = cz = 0.0f;
     n = __builtin_inff();
     err = 0.0f;
     bh = 0.0f;
@@ -229,8 +238,8 @@ struct Closest<true> {
       const float band = cerr + err;
       if (cn < -cerr || cn > n + band) return;
       bool accept = cn > cerr && cn < n - band;
-      if (!accept) {
-        // too close to call: the exact rule
+      if (__builtin_expect(!accept, 0)) {
+        // too close to call: the exact rule (rare: the compiler keeps it off the straight path)
         const float ne = -cbh - ieee_sqrt(cdisc);
         if (ne > -1e-30f) {
           const float qe = ieee_div(ne, a);
@@ -249,6 +258,9 @@ struct Closest<true> {
         bh = cbh;
         disc = cdisc;
         idx = i;
+        cx = g.x;
+        cy = g.y;
+        cz = g.z;
       }
     }
   }
@@ -260,29 +272,61 @@ struct Closest<true> {
     Hit h;
     h.idx = idx != kNoHit ? idx : -1;
     h.dst = dst();
+    h.cx = cx;
+    h.cy = cy;
+    h.cz = cz;
     return h;
   }
 };
 
 // skip: id of the triangle the ray starts on (-1: none); a planar primitive cannot be hit
 // again by a ray that leaves it, and the triangle test has no epsilon.
-template <bool APPROX>
+// Four consecutive geometry records (the array is padded to a multiple of four).
+struct SphereGroup {
+  float4 g0, g1, g2, g3;
+};
+__device__ __forceinline__ SphereGroup load_group(const Scene &S, uint32_t i) {
+  const ConstF4 *geom = (const ConstF4 *)S.geom + i;
+  SphereGroup G;
+  G.g0 = load_const(geom);
+  G.g1 = load_const(geom + 1);
+  G.g2 = load_const(geom + 2);
+  G.g3 = load_const(geom + 3);
+  return G;
+}
+
+// GROUPED: spheres are fetched four at a time, for code whose running time is one wave's
+// chain of dependent segments rather than the device's throughput.
+template <bool APPROX, bool GROUPED = false>
 __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int skip) {
   const float a = dot(d, d);
   Closest<APPROX> C;
   C.reset(a);
   const uint32_t n = S.n_spheres;
-  // The scene is read-only for the whole launch.  Reading it through the constant address
-  // space tells the compiler so, and a wave-uniform index then becomes a scalar load (one
-  // fetch per wave through the scalar cache) instead of a vector load of 64 equal addresses.
-  const ConstF4 *geom = (const ConstF4 *)S.geom;
-  // the next sphere is fetched while the current one is tested
-  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (n) g = load_const(geom);
-  for (uint32_t i = 0; i < n; ++i) {
-    const float4 g_next = load_const(geom + (i + 1u < n ? i + 1u : i));
-    C.sphere(g, (int)i, o, d, a);
-    g = g_next;
+  if constexpr (GROUPED) {
+    // Each step is one 64-byte scalar fetch and the loop bookkeeping is paid once per four
+    // tests: 7 % off the chain of a wave that runs alone, nothing for a device full of waves
+    // (which hide the bookkeeping behind each other's arithmetic).
+    for (uint32_t i = 0; i < n; i += 4u) {
+      const SphereGroup G = load_group(S, i);
+      C.sphere(G.g0, (int)i, o, d, a);
+      if (i + 1u < n) C.sphere(G.g1, (int)(i + 1u), o, d, a);
+      if (i + 2u < n) C.sphere(G.g2, (int)(i + 2u), o, d, a);
+      if (i + 3u < n) C.sphere(G.g3, (int)(i + 3u), o, d, a);
+    }
+  } else {
+    // The scene is read-only for the whole launch.  Reading it through the constant address
+    // space tells the compiler so, and a wave-uniform index then becomes a scalar load (one
+    // fetch per wave through the scalar cache) instead of a vector load of 64 equal addresses.
+    const ConstF4 *geom = (const ConstF4 *)S.geom;
+    // the next sphere is fetched while the current one is tested
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n) g = load_const(geom);
+    for (uint32_t i = 0; i < n; ++i) {
+      const float4 g_next = load_const(geom + (i + 1u < n ? i + 1u : i));
+      C.sphere(g, (int)i, o, d, a);
+      g = g_next;
+    }
   }
   for (uint32_t t = 0; t < S.n_tris; ++t) {
     const int id = (int)(n + t);
@@ -391,15 +435,24 @@ __device__ __forceinline__ f3 texture_sample(const Texture &T, float u, float v)
 // segment must skip (the triangle itself) or -1.
 // The normal steers only later segments, never the id of the hit itself, so the fast policy
 // normalises it with the hardware reciprocal square root like the other sampling code.
-template <bool STRICT>
-__device__ __forceinline__ int hit_surface(const Scene &S, int idx, float dst, f3 o, f3 d, f3 &p,
+// NO_MESH: the launch has no triangles (their branch is compiled out).  CENTRE: h carries the
+// sphere's centre.
+template <bool STRICT, bool NO_MESH, bool CENTRE>
+__device__ __forceinline__ int hit_surface(const Scene &S, const Hit &h, f3 o, f3 d, f3 &p,
                                            f3 &n, float4 &m_colour, float4 &m_emission,
                                            float4 &m_specular) {
-  p = fma3(d, dst, o);
+  const int idx = h.idx;
+  p = fma3(d, h.dst, o);
   int mat, skip;
-  if ((uint32_t)idx < S.n_spheres) {
-    const float4 g = scene_f4(S.geom, (uint32_t)idx);
-    n = Math<STRICT>::normalize(p - mk3(g.x, g.y, g.z));
+  if (NO_MESH || (uint32_t)idx < S.n_spheres) {
+    f3 centre;
+    if constexpr (CENTRE) {
+      centre = mk3(h.cx, h.cy, h.cz);
+    } else {
+      const float4 g = scene_f4(S.geom, (uint32_t)idx);
+      centre = mk3(g.x, g.y, g.z);
+    }
+    n = Math<STRICT>::normalize(p - centre);
     mat = idx;
     skip = -1;
   } else {

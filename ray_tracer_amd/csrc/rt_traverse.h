@@ -126,10 +126,10 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
 }
 
 // closest hit through whichever structure the kernel was built for
-template <bool BVH, bool APPROX>
+template <bool BVH, bool APPROX, bool GROUPED = false>
 __device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stack, int skip) {
   if constexpr (BVH) return closest_hit_bvh<false, APPROX>(S, o, d, stack, skip);
-  else return closest_hit_brute<APPROX>(S, o, d, skip);
+  else return closest_hit_brute<APPROX, GROUPED>(S, o, d, skip);
 }
 
 // ---- a search whose state outlives the loop iteration ----------------------------------
@@ -212,12 +212,13 @@ constexpr int bvh_stack_words() { return BVH ? kBvhStack * kBlockThreads : 1; }
 // next segment must skip.  TEX kernels (launched only while a texture is bound) replace the
 // material colour by the texture sample; its coordinates are taken at the hit and the
 // texels are fetched last, when little else is live.  Kernels without TEX carry none of it.
-template <bool STRICT, bool TEX>
-__device__ __forceinline__ int shade_hit(const Scene &S, Hit h, uint32_t &rng, f3 &o, f3 &d,
+// NO_MESH and CENTRE as in hit_surface.
+template <bool STRICT, bool TEX, bool NO_MESH = false, bool CENTRE = false>
+__device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, uint32_t &rng, f3 &o, f3 &d,
                                          f3 &light, f3 &colour) {
   f3 p, n;
   float4 mc, me, ms;
-  const int skip = hit_surface<STRICT>(S, h.idx, h.dst, o, d, p, n, mc, me, ms);
+  const int skip = hit_surface<STRICT, NO_MESH, CENTRE>(S, h, o, d, p, n, mc, me, ms);
   bool textured = false;
   float tu = 0.0f, tv = 0.0f;
   if constexpr (TEX) {

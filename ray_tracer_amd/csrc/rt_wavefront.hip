@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, u
       uint32_t s = sb >> 16, b = sb & 0xffffu;
       f3 o = mk3(p0.x, p0.y, p0.z), d = mk3(p1.x, p1.y, p1.z);
       f3 colour = mk3(p2.x, p2.y, p2.z), light = mk3(p3.x, p3.y, p3.z);
-      Hit h;
+      Hit h{};
       h.dst = hrec.x;
       h.idx = idx;
       const int skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_wf_drain_tree(Params P, Scene S, WfView
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {

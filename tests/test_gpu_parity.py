@@ -206,6 +206,24 @@ def test_two_calls_continue_the_progressive_image(oracle):
         assert r.stats().rays == 0
 
 
+def test_launches_after_the_tile_order_exists_match_the_oracle(oracle):
+    """From its second launch on a context renders heaviest tiles first, and a brute-force scene
+    then runs its first blocks through one loop of k_mega_regen and the rest through the other:
+    five single-frame launches must still equal the oracle's five frames bit for bit."""
+    w, h = 176, 112
+    ubo = rt.make_ubo(w, h, 3, 9, sun_intensity=1.5)
+    sph = rt.default_scene()
+    want = oracle.render(ubo, sph, w, h, 0, 5, 1)
+    with rt.Renderer(w, h, flags=rt.FLAG_STRICT_MATH) as r:
+        r.set_params(ubo)
+        r.set_spheres(sph)
+        for f in range(5):
+            r.render(f, 1, 1)
+        assert np.array_equal(r.read_rgba8(), want["rgba8"])
+        assert np.array_equal(_bits(r.read_accum()), _bits(want["accum"]))
+        assert r.stats().rays == want["rays"]
+
+
 def test_rotated_camera_and_linear_accum(oracle):
     w, h = 120, 80
     ubo = rt.make_ubo(w, h, 2, 10, pitch=0.25, yaw=-0.4)
@@ -786,11 +804,12 @@ def test_fast_policy_ids_exact_on_random_scenes(oracle, accel):
         assert np.array_equal(got["ids"], want["ids"]), f"seed {seed}"
 
 
-def test_batched_and_plain_regen_loops_are_bit_identical():
-    """k_mega_regen has a throughput form (path ends gathered per wave) chosen by tile count.
-    The choice is read once per process (RT_REGEN_BATCH_TILES), so two child processes render
-    the same frames with either loop forced; images, ids and ray counts must be identical."""
-    import hashlib
+def test_regen_loop_forms_are_bit_identical():
+    """k_mega_regen has two loops (the plain one and a throughput form that gathers path ends per
+    wave) and a mixed launch that runs the heaviest tiles through the first and the rest through
+    the second.  The choice is read once per process (RT_REGEN_FORM), so child processes render
+    the same frames with each form forced; images, ids and ray counts must be identical.  The
+    mixed form needs a measured tile order, which exists from the second launch on."""
     import os
     import subprocess
     import sys
@@ -800,15 +819,17 @@ def test_batched_and_plain_regen_loops_are_bit_identical():
         "w, h = 328, 200\n"
         "with rt.Renderer(w, h) as r:\n"
         "    r.set_params(rt.make_ubo(w, h, 6, 12, sun_intensity=2.0)); r.set_spheres(rt.default_scene())\n"
-        "    r.render(0, 3, 1); r.sync()\n"
+        "    for f in range(4):\n"
+        "        r.render(f, 1, 1)\n"
+        "    r.sync()\n"
         "    m = hashlib.sha256()\n"
         "    m.update(r.read_accum().tobytes()); m.update(r.read_rgba8().tobytes()); m.update(r.read_primary_ids().tobytes())\n"
         "    print('DIGEST', m.hexdigest(), r.stats().rays)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
-    for tiles in ("0", "4000000000"):
-        env = dict(os.environ, RT_REGEN_BATCH_TILES=tiles, PYTHONPATH=root)
+    for form in ("plain", "batched", "mixed"):
+        env = dict(os.environ, RT_REGEN_FORM=form, RT_REGEN_CHAIN_DIV="4", PYTHONPATH=root)
         res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
         assert res.returncode == 0, res.stderr
         out.append([l for l in res.stdout.splitlines() if l.startswith("DIGEST")][0])
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2], out
