@@ -194,6 +194,7 @@ struct Closest<false> {
     best.cx = best.cy = best.cz = 0.0f;
     best_n = __builtin_inff();
   }
+  template <bool LIKELY = false>
   __device__ __forceinline__ void sphere(float4 g, int idx, f3 o, f3 d, float a) {
     sphere_candidate_tie(g, idx, o, d, a, best_n, best);
   }
@@ -225,12 +226,15 @@ struct Closest<true> {
     rcp_a = __builtin_amdgcn_rcpf(a);
     idx = kNoHit;
   }
+  // LIKELY: the caller expects most tests to find the sphere in front of the ray (code
+  // layout only)
+  template <bool LIKELY = false>
   __device__ __forceinline__ void sphere(float4 g, int i, f3 o, f3 d, float a) {
     f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
     const float cbh = dot(oc, d);
     const float c = dot(oc, oc) - g.w;
     const float cdisc = __builtin_fmaf(cbh, cbh, -(a * c));
-    if (cdisc >= 0.0f && cbh <= 0.0f) {
+    if (__builtin_expect(cdisc >= 0.0f && cbh <= 0.0f, LIKELY)) {
       const float s = __builtin_amdgcn_sqrtf(cdisc);
       const float cn = -cbh - s;
       // E plus a floor that keeps denormal-small numerators out of the shortcuts
@@ -309,10 +313,10 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int
     // (which hide the bookkeeping behind each other's arithmetic).
     for (uint32_t i = 0; i < n; i += 4u) {
       const SphereGroup G = load_group(S, i);
-      C.sphere(G.g0, (int)i, o, d, a);
-      if (i + 1u < n) C.sphere(G.g1, (int)(i + 1u), o, d, a);
-      if (i + 2u < n) C.sphere(G.g2, (int)(i + 2u), o, d, a);
-      if (i + 3u < n) C.sphere(G.g3, (int)(i + 3u), o, d, a);
+      C.template sphere<true>(G.g0, (int)i, o, d, a);
+      if (i + 1u < n) C.template sphere<true>(G.g1, (int)(i + 1u), o, d, a);
+      if (i + 2u < n) C.template sphere<true>(G.g2, (int)(i + 2u), o, d, a);
+      if (i + 3u < n) C.template sphere<true>(G.g3, (int)(i + 3u), o, d, a);
     }
   } else {
     // The scene is read-only for the whole launch.  Reading it through the constant address
