@@ -265,7 +265,11 @@ def main() -> None:
                 "wavefront_ms_per_frame_1080p_64spp": other_ms,
             },
             "roofline": {
-                "bound": "valu",
+                # the contract's two bounds are "hbm" and "mfma": this is the compute one.  The kernel
+                # issues no MFMA (there is no dense contraction in a path tracer); its arithmetic is
+                # FP32 vector work, priced against the f32 peak, which is the same 157.3 TFLOP/s
+                "bound": "mfma",
+                "compute_unit": "valu",
                 "kernel": {"megakernel": "k_mega_regen<fast,brute>", "nested": "k_mega_nested<fast,brute>",
                            "wavefront": "wavefront stages"}[args.mode],
                 "achieved": achieved,
@@ -274,9 +278,9 @@ def main() -> None:
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                # from the same committed counter passes: share of the launch the vector ALUs were
-                # issuing, and share of the 64 lanes active per issued instruction
-                "valu_busy": pmc.get("valu_busy"),
+                # from the same committed counter passes: wave-level VALU instructions per SIMD-cycle
+                # over what a SIMD was measured to issue, and share of the 64 lanes active per instruction
+                "valu_issue_frac": pmc.get("valu_issue_frac"),
                 "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
                 "launch_ms": launch_ms,
                 "algorithmic_flops_per_launch": flops,

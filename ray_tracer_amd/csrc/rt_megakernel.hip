@@ -20,6 +20,9 @@
 #ifndef RT_REGEN_END_BATCH
 #define RT_REGEN_END_BATCH 8   // ended paths a wave gathers before it runs the path-end code
 #endif
+#ifndef RT_REGEN_BATCHED_WAVES
+#define RT_REGEN_BATCHED_WAVES 7  // waves per SIMD the untextured batched loop is compiled for (72 VGPR; 6: +2 %, 8: +4 % time at 3840x2160)
+#endif
 #ifndef RT_REGEN_MIXED_WAVES
 #define RT_REGEN_MIXED_WAVES 1
 #endif
@@ -123,7 +126,7 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
 // (whose job is throughput).
 constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
 template <bool STRICT, bool BVH, bool TEX, bool APPROX, int FORM>
-__global__ __launch_bounds__(256, FORM == kRegenMixed ? RT_REGEN_MIXED_WAVES : RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+__global__ __launch_bounds__(256, FORM == kRegenMixed ? RT_REGEN_MIXED_WAVES : (FORM == kRegenBatched && !TEX && !STRICT) ? RT_REGEN_BATCHED_WAVES : RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
   // The plain loop is used where one wave's chain of segments sets the launch time: its
   // brute-force search is the form tuned for a wave running alone, and the hit carries the

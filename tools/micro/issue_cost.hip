@@ -16,6 +16,7 @@
     asm volatile("s_nop 0" ::"v"(a), "v"(b), "v"(c), "v"(d));                               \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();                            \
     if (threadIdx.x == 0) out[0] = t1 - t0;                                                  \
+    if (threadIdx.x == blockDim.x - 64) out[2] = t1 - t0;                                    \
     if (a + b + c + d == 12345.678f) out[1] = 1;                                             \
   }                                                                                          \
   __global__ void name##_dep(unsigned long long *out, float seed) {                          \
@@ -25,6 +26,7 @@
     asm volatile("s_nop 0" ::"v"(a), "v"(b), "v"(c), "v"(d));                               \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();                            \
     if (threadIdx.x == 0) out[0] = t1 - t0;                                                  \
+    if (threadIdx.x == blockDim.x - 64) out[2] = t1 - t0;                                    \
     if (a + b + c + d == 12345.678f) out[1] = 1;                                             \
   }
 
@@ -97,9 +99,25 @@ __global__ void k_branch_dep(unsigned long long *out, float seed) {  // not-take
   if (threadIdx.x == 0) out[0] = t1 - t0;
 }
 
-int main() {
+int main(int argc, char **argv) {
   unsigned long long *d;
-  hipMalloc(&d, 16);
+  (void)hipMalloc(&d, 32);
+  if (argc > 1) {
+    // waves per SIMD: one block of 64 * 4 * n threads puts n waves on each SIMD of one CU;
+    // thread 0 times its own wave's stream while the others run the same one beside it
+    for (int n = 1; n <= 4; ++n) {
+      unsigned long long a[3], b[3];
+      for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_add_ind, dim3(1), dim3(256 * n), 0, 0, d, 1.5f);
+        (void)hipMemcpy(a, d, 24, hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(k_add_dep, dim3(1), dim3(256 * n), 0, 0, d, 1.5f);
+        (void)hipMemcpy(b, d, 24, hipMemcpyDeviceToHost);
+      }
+      printf("%d wave(s) per SIMD: v_add_f32 cycles per instruction per wave: independent %.2f (oldest wave) %.2f (youngest), dependent %.2f / %.2f\n",
+             n, a[0] / (256.0 * 128.0), a[2] / (256.0 * 128.0), b[0] / (256.0 * 32.0), b[2] / (256.0 * 32.0));
+    }
+    return 0;
+  }
   struct { const char *name; void (*ind)(unsigned long long *, float); void (*dep)(unsigned long long *, float); } T[] = {
 #define E(n) {#n, n##_ind, n##_dep}
       E(k_add), E(k_mul_lo), E(k_mul_hi), E(k_mul24), E(k_addu), E(k_xor), E(k_lshr), E(k_sqrt), E(k_log), E(k_cos),
@@ -108,13 +126,14 @@ int main() {
     unsigned long long r[2][2];
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL(t.ind, dim3(1), dim3(64), 0, 0, d, 1.5f);
-      hipMemcpy(&r[0], d, 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&r[0], d, 8, hipMemcpyDeviceToHost);
       hipLaunchKernelGGL(t.dep, dim3(1), dim3(64), 0, 0, d, 1.5f);
-      hipMemcpy(&r[1], d, 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&r[1], d, 8, hipMemcpyDeviceToHost);
     }
     const double n = 256.0 * 32.0;
-    const double ni = (t.ind == k_mix_ind) ? n : n;
-    printf("%-10s independent %.2f cyc/instr   dependent %.2f cyc/instr\n", t.name, r[0][0] / ni, r[1][0] / n);
+    // the independent bodies hold four instructions per copy
+    const bool four = t.ind != k_branch_ind;
+    printf("%-10s independent %.2f cyc/instr   dependent %.2f cyc/instr\n", t.name, r[0][0] / (four ? 4.0 * n : n), r[1][0] / n);
   }
   return 0;
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small fixed workloads for rocprofv3 counter passes.
 
-    rocprofv3 --pmc <counters> --output-format csv -d out -- python3 tools/prof_render.py [mode] [scene] [frames]
+    rocprofv3 --pmc <counters> --output-format csv -d out -- python3 tools/prof_render.py [mode] [scene] [frames] [WxH]
 scene: default (3 spheres, 1920x1080, 64 spp) | grid (10k spheres, 8 spp) | terrain (1M triangles, 8 spp, 8 bounces)
 """
 import os
@@ -16,6 +16,8 @@ scene = sys.argv[2] if len(sys.argv) > 2 else "default"
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 flags = rt.FLAG_COUNT_TRAVERSAL if os.environ.get("RT_COUNT") else 0
 w, h, spp, bounces = 1920, 1080, 8, 25
+if len(sys.argv) > 4:
+    w, h = (int(v) for v in sys.argv[4].split("x"))
 mesh = None
 if scene == "default":
     spp, sph = 64, rt.default_scene()
