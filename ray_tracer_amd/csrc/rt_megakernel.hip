@@ -23,9 +23,6 @@
 #ifndef RT_REGEN_BATCHED_WAVES
 #define RT_REGEN_BATCHED_WAVES 7  // waves per SIMD the untextured batched loop is compiled for (72 VGPR; 6: +2 %, 8: +4 % time at 3840x2160)
 #endif
-#ifndef RT_REGEN_MIXED_WAVES
-#define RT_REGEN_MIXED_WAVES 1
-#endif
 #ifndef RT_REGEN_CHAIN_DIV
 #define RT_REGEN_CHAIN_DIV 32u  // a mixed launch runs its first n_tiles / 32 blocks through the plain loop (8..128 within 2 %)
 #endif
@@ -125,8 +122,12 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
 // tiles with the longest chains, which set the launch time) and the batched loop for the rest
 // (whose job is throughput).
 constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
+// waves per SIMD a form is compiled for (the register budget follows from it)
+constexpr int regen_waves(bool strict, bool tex, int form) {
+  return form == kRegenBatched && !tex && !strict ? RT_REGEN_BATCHED_WAVES : RT_MEGA_WAVES;
+}
 template <bool STRICT, bool BVH, bool TEX, bool APPROX, int FORM>
-__global__ __launch_bounds__(256, FORM == kRegenMixed ? RT_REGEN_MIXED_WAVES : (FORM == kRegenBatched && !TEX && !STRICT) ? RT_REGEN_BATCHED_WAVES : RT_MEGA_WAVES) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+__global__ __launch_bounds__(256, regen_waves(STRICT, TEX, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
   // The plain loop is used where one wave's chain of segments sets the launch time: its
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
