@@ -6,8 +6,15 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracer_amd as rt
 w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
+scene = os.environ.get("LONE_SCENE", "default")   # default | grid (10k spheres, 8 spp) | terrain (1M triangles, 8 spp, 8 bounces)
 with rt.Renderer(w, h) as r:
-    r.set_params(rt.make_ubo(w, h, 64, 25)); r.set_spheres(rt.default_scene())
+    if scene == "default":
+        r.set_params(rt.make_ubo(w, h, 64, 25)); r.set_spheres(rt.default_scene())
+    elif scene == "grid":
+        r.set_params(rt.make_ubo(w, h, 8, 25)); r.set_spheres(rt.grid_spheres_scene(10000))
+    else:
+        r.set_params(rt.make_ubo(w, h, 8, 8)); r.set_spheres(rt.default_scene()[:2])
+        r.set_mesh(*rt.terrain_mesh(709), rt.matte(0.55, 0.5, 0.4, smoothness=0.7, specular_probability=0.15))
     for f in range(20):   # the order settles; later refreshes come every 16th launch
         r.render(0, 1, 1)
     r.stats()

@@ -72,6 +72,7 @@ __global__ void k_pk_ind(unsigned long long *out, float seed) {
   asm volatile("s_nop 0" ::"v"(a), "v"(b), "v"(c), "v"(d));
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) out[0] = t1 - t0;
+  if (threadIdx.x == blockDim.x - 64) out[2] = t1 - t0;
   if (a.x + b.x + c.x + d.y == 12345.678f) out[1] = 1;
 }
 __global__ void k_pk_dep(unsigned long long *out, float seed) {
@@ -115,6 +116,14 @@ int main(int argc, char **argv) {
       }
       printf("%d wave(s) per SIMD: v_add_f32 cycles per instruction per wave: independent %.2f (oldest wave) %.2f (youngest), dependent %.2f / %.2f\n",
              n, a[0] / (256.0 * 128.0), a[2] / (256.0 * 128.0), b[0] / (256.0 * 32.0), b[2] / (256.0 * 32.0));
+      for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_pk_ind, dim3(1), dim3(256 * n), 0, 0, d, 1.5f);
+        (void)hipMemcpy(a, d, 24, hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(k_sqrt_ind, dim3(1), dim3(256 * n), 0, 0, d, 1.5f);
+        (void)hipMemcpy(b, d, 24, hipMemcpyDeviceToHost);
+      }
+      printf("                    v_pk_fma_f32 independent %.2f / %.2f, v_sqrt_f32 independent %.2f / %.2f\n",
+             a[0] / (256.0 * 128.0), a[2] / (256.0 * 128.0), b[0] / (256.0 * 128.0), b[2] / (256.0 * 128.0));
     }
     return 0;
   }
