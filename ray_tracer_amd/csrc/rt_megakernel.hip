@@ -20,6 +20,9 @@
 #ifndef RT_REGEN_END_BATCH
 #define RT_REGEN_END_BATCH 8   // ended paths a wave gathers before it runs the path-end code
 #endif
+#ifndef RT_SCHED_WAVES
+#define RT_SCHED_WAVES 5  // waves per SIMD the untextured fast k_mega_sched is compiled for (96 VGPR; 10k spheres at 3840x2160: 5.68 against 5.90 ms)
+#endif
 #ifndef RT_REGEN_BATCHED_WAVES
 #define RT_REGEN_BATCHED_WAVES 7  // waves per SIMD the untextured batched loop is compiled for (72 VGPR; 6: +2 %, 8: +4 % time at 3840x2160)
 #endif
@@ -97,13 +100,27 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
 #ifndef RT_PRIO_TOP
 #define RT_PRIO_TOP 16   // ranks below n_tiles / RT_PRIO_TOP run at priority 3
 #endif
-__device__ __forceinline__ uint32_t ordered_tile(const Outputs &O) {
-  if (!O.tile_order) return blockIdx.x;
-  const uint32_t rank = blockIdx.x;
+__device__ __forceinline__ uint32_t ordered_tile(const Outputs &O, uint32_t rank) {
+  if (!O.tile_order) return rank;
   if (rank * RT_PRIO_TOP < O.n_tiles) __builtin_amdgcn_s_setprio(3);
   else if (rank * (RT_PRIO_TOP / 4) < O.n_tiles) __builtin_amdgcn_s_setprio(2);
   else if (rank * (RT_PRIO_TOP / 16) < O.n_tiles) __builtin_amdgcn_s_setprio(1);
   return O.tile_order[rank];
+}
+
+// Threads per block of k_mega_sched and of the brute-force k_mega_regen.  A tile is 16x16
+// pixels = four waves.  With kTileBlock = 64 each wave is a block of its own (four consecutive
+// blocks per tile), so a wave that finishes frees its slot, registers and stack at once
+// instead of holding them until the slowest wave of its tile is done.
+#ifndef RT_WAVE_BLOCKS
+#define RT_WAVE_BLOCKS 1
+#endif
+constexpr int kTileBlock = RT_WAVE_BLOCKS ? 64 : 256;
+template <int BLOCK>
+__device__ __forceinline__ uint32_t tile_rank() { return BLOCK == 64 ? blockIdx.x >> 2 : blockIdx.x; }
+template <int BLOCK>
+__device__ __forceinline__ uint32_t tile_thread() {
+  return BLOCK == 64 ? ((blockIdx.x & 3u) << 6) | threadIdx.x : threadIdx.x;
 }
 
 // per-wave epilogue: path segments into the ray counter, slowest pixel into the tile's cost
@@ -127,16 +144,18 @@ constexpr int regen_waves(bool strict, bool tex, int form) {
   return form == kRegenBatched && !tex && !strict ? RT_REGEN_BATCHED_WAVES : RT_MEGA_WAVES;
 }
 template <bool STRICT, bool BVH, bool TEX, bool APPROX, int FORM>
-__global__ __launch_bounds__(256, regen_waves(STRICT, TEX, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+__global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   __shared__ int stack[bvh_stack_words<BVH>()];
   // The plain loop is used where one wave's chain of segments sets the launch time: its
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
   // sphere's centre to the shading code instead of having it fetched again.
   constexpr bool CHAIN = !BVH;
-  const bool batched = FORM == kRegenMixed ? blockIdx.x >= O.chain_ranks : FORM == kRegenBatched;
-  const uint32_t tile = ordered_tile(O);
+  constexpr int BLOCK = BVH ? 256 : kTileBlock;
+  const uint32_t rank = tile_rank<BLOCK>(), tile_t = tile_thread<BLOCK>();
+  const bool batched = FORM == kRegenMixed ? rank >= O.chain_ranks : FORM == kRegenBatched;
+  const uint32_t tile = ordered_tile(O, rank);
   uint32_t px, py;
-  pixel_of_tile(tile, O.tiles_x, px, py);
+  pixel_of_tile(tile, O.tiles_x, tile_t, px, py);
   uint32_t nrays = 0;
 #ifdef RT_MEASURE_TIMELINE
   const unsigned long long t_begin = wall_clock64();
@@ -265,7 +284,7 @@ __global__ __launch_bounds__(256, regen_waves(STRICT, TEX, FORM)) void k_mega_re
   const uint32_t wsum = wave_sum_u32(nrays), wmax = wave_max_u32(nrays);
   if ((threadIdx.x & 63u) == 0) {
     const unsigned long long t_end = wall_clock64();
-    int *rec = O.ids + 6u * (size_t)(tile * 4u + (threadIdx.x >> 6));
+    int *rec = O.ids + 6u * (size_t)(tile * 4u + (tile_t >> 6));
     rec[0] = (int)(uint32_t)t_begin;
     rec[1] = (int)(uint32_t)(t_begin >> 32);
     rec[2] = (int)(uint32_t)t_end;
@@ -303,11 +322,11 @@ __global__ __launch_bounds__(256, regen_waves(STRICT, TEX, FORM)) void k_mega_re
 #endif
 
 template <bool STRICT, bool TEX, bool APPROX>
-__global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
-  __shared__ int stack[kBvhStack * kBlockThreads];
-  const uint32_t tile = ordered_tile(O);
+__global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
+  __shared__ int stack[kBvhStack * kTileBlock];
+  const uint32_t tile = ordered_tile(O, tile_rank<kTileBlock>());
   uint32_t px, py;
-  pixel_of_tile(tile, O.tiles_x, px, py);
+  pixel_of_tile(tile, O.tiles_x, tile_thread<kTileBlock>(), px, py);
   uint32_t nrays = 0;
   bool active = px < P.width && py < P.height && F.count;
   const size_t pix = active ? (size_t)py * P.width + px : 0;
@@ -348,16 +367,16 @@ __global__ __launch_bounds__(256) void k_mega_sched(Params P, Scene S, FrameSeq 
       // third of an inner step.  (Re-counting the lanes after every step to stop early
       // costs more than the empty lanes it saves: 5.4 ms against 5.1 ms on the terrain.)
       if (want_inner) {
-        search_inner_step(S, Q, stack);
+        search_inner_step<kTileBlock>(S, Q, stack);
 #pragma unroll
         for (int rep = 1; rep < RT_SCHED_INNER_REPS; ++rep)
-          if (Q.node >= 0) search_inner_step(S, Q, stack);
+          if (Q.node >= 0) search_inner_step<kTileBlock>(S, Q, stack);
       }
     } else if (w_leaf >= w_shade) {
       RT_SCHED_TALLY(2, n_leaf);
       if (want_leaf) {
         leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best);
-        Q.node = search_pop(Q, stack);
+        Q.node = search_pop<kTileBlock>(Q, stack);
       }
     } else {
       RT_SCHED_TALLY(3, n_shade);
@@ -422,6 +441,8 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
   }
 #endif
   dim3 block(256, 1, 1);
+  // kernels whose blocks are single waves: four blocks per tile
+  const dim3 wave_tiles(tiles.x * (256u / kTileBlock), 1, 1), wave_block(kTileBlock, 1, 1);
   // k_mega_regen and k_mega_sched need at least one sample and one bounce
   static const bool sched = [] {
     const char *e = getenv("RT_MEGA_SCHED");
@@ -444,7 +465,7 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
   if (nested)
     hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX, APPROX>), grid, block, 0, stream, P, S, F, O);
   else if (BVH && sched)
-    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX, APPROX>), tiles, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX, APPROX>), wave_tiles, wave_block, 0, stream, P, S, F, O);
   else if (BVH)
     hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, O);
   else {
@@ -458,11 +479,11 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     Q.chain_ranks = (O.n_tiles + chain_div - 1u) / chain_div;
     constexpr bool B = !BVH;  // keeps the BVH instantiations of the brute-force forms out of the library
     if (form == kRegenMixed)
-      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenMixed : kRegenPlain>), tiles, block, 0, stream, P, S, F, Q);
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenMixed : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else if (form == kRegenBatched)
-      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenBatched : kRegenPlain>), tiles, block, 0, stream, P, S, F, Q);
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenBatched : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else
-      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, Q);
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
   }
   return hipGetLastError();
 }

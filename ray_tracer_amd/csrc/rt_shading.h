@@ -540,8 +540,8 @@ __device__ __forceinline__ void pixel_of_thread(uint32_t &px, uint32_t &py) {
 }
 
 // the same layout for a tile picked from a launch-order table
-__device__ __forceinline__ void pixel_of_tile(uint32_t tile, uint32_t tiles_x, uint32_t &px, uint32_t &py) {
-  const uint32_t t = threadIdx.x;
+// t: index of the thread within the tile's 256 (threadIdx.x when a block is a tile)
+__device__ __forceinline__ void pixel_of_tile(uint32_t tile, uint32_t tiles_x, uint32_t t, uint32_t &px, uint32_t &py) {
   const uint32_t wave = t >> 6, lane = t & 63u;
   px = (tile % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
   py = (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);

@@ -177,13 +177,14 @@ __device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search<
   else Q.node = 0;
 }
 
-template <bool APPROX>
+// STRIDE: threads per block of the calling kernel (the stack is [entry][thread])
+template <int STRIDE = kBlockThreads, bool APPROX>
 __device__ __forceinline__ int search_pop(Search<APPROX> &Q, const int *stack) {
   if (Q.sp == 0) return kSearchOver;
-  return stack[(--Q.sp) * kBlockThreads + threadIdx.x];
+  return stack[(--Q.sp) * STRIDE + threadIdx.x];
 }
 
-template <bool APPROX>
+template <int STRIDE = kBlockThreads, bool APPROX>
 __device__ __forceinline__ void search_inner_step(const Scene &S, Search<APPROX> &Q, int *stack) {
   const BvhNode nd = load_node(S.nodes, Q.node);
   const float best_dst = Q.best.dst();
@@ -195,12 +196,12 @@ __device__ __forceinline__ void search_inner_step(const Scene &S, Search<APPROX>
   const bool go1 = t1 < __builtin_inff() && c1 != (int)kNullLeaf;
   if (go0 && go1) {
     const bool first0 = t0 <= t1;
-    stack[(Q.sp++) * kBlockThreads + threadIdx.x] = first0 ? c1 : c0;
+    stack[(Q.sp++) * STRIDE + threadIdx.x] = first0 ? c1 : c0;
     Q.node = first0 ? c0 : c1;
   } else if (go0 || go1) {
     Q.node = go0 ? c0 : c1;
   } else {
-    Q.node = search_pop(Q, stack);
+    Q.node = search_pop<STRIDE>(Q, stack);
   }
 }
 
