@@ -95,6 +95,7 @@ struct Outputs {
   uint32_t *tile_cost;
   uint32_t tiles_x, n_tiles;
   uint32_t chain_ranks;     // k_mega_regen, mixed form: blocks below this rank run the plain loop
+  uint32_t probe;           // 1: a cost probe, the tile kernels write tile_cost and nothing else
 };
 
 }  // namespace rt

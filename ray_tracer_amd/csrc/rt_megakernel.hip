@@ -124,11 +124,12 @@ __device__ __forceinline__ uint32_t tile_thread() {
 }
 
 // per-wave epilogue: path segments into the ray counter, slowest pixel into the tile's cost
+// (a probe launch records costs and nothing else)
 __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint32_t nrays) {
   const uint32_t wsum = wave_sum_u32(nrays);
   const uint32_t wmax = wave_max_u32(nrays);
   if ((threadIdx.x & 63u) == 0) {
-    if (wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+    if (wsum && !O.probe) atomicAdd(O.rays, (unsigned long long)wsum);
     if (O.tile_cost) atomicMax(O.tile_cost + tile, wmax);
   }
 }
@@ -271,11 +272,13 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
         }
       }
     }
-    O.accum[pix] = acc;
-    O.rgba8[pix] = img;
+    if (!O.probe) {
+      O.accum[pix] = acc;
+      O.rgba8[pix] = img;
 #ifndef RT_MEASURE_TIMELINE
-    O.ids[pix] = id0;
+      O.ids[pix] = id0;
 #endif
+    }
   }
   tally_wave(O, tile, nrays);
 #ifdef RT_MEASURE_TIMELINE
@@ -419,9 +422,11 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1)
       if (active) {
         search_begin(S, o, d, Q);
       } else {
-        O.accum[pix] = acc;
-        O.rgba8[pix] = img;
-        O.ids[pix] = id0;
+        if (!O.probe) {
+          O.accum[pix] = acc;
+          O.rgba8[pix] = img;
+          O.ids[pix] = id0;
+        }
       }
     }
   }

@@ -224,6 +224,24 @@ def test_launches_after_the_tile_order_exists_match_the_oracle(oracle):
         assert r.stats().rays == want["rays"]
 
 
+@pytest.mark.parametrize("scene", ["default", "grid"])
+def test_cost_probe_before_a_first_launch_leaves_no_trace(oracle, scene):
+    """A context's first launch of 32 or more samples per pixel is preceded by a two-sample
+    probe that measures tile costs: image, ids and ray count must be the oracle's all the same."""
+    w, h = 72, 40
+    ubo = rt.make_ubo(w, h, 33, 6, sun_intensity=1.5)
+    sph = rt.default_scene() if scene == "default" else rt.grid_spheres_scene(40)
+    want = oracle.render(ubo, sph, w, h, 0, 1, 1)
+    with rt.Renderer(w, h, flags=rt.FLAG_STRICT_MATH) as r:
+        r.set_params(ubo)
+        r.set_spheres(sph)
+        r.render(0, 1, 1)
+        assert np.array_equal(r.read_rgba8(), want["rgba8"])
+        assert np.array_equal(_bits(r.read_accum()), _bits(want["accum"]))
+        assert np.array_equal(r.read_primary_ids(), want["ids"])
+        assert r.stats().rays == want["rays"]
+
+
 def test_rotated_camera_and_linear_accum(oracle):
     w, h = 120, 80
     ubo = rt.make_ubo(w, h, 2, 10, pitch=0.25, yaw=-0.4)
