@@ -165,7 +165,7 @@ def main() -> None:
         """finish the step that last used image k: its sum, then rank 0's 8-bit image"""
         if in_flight[k]:
             end_sum(pending[k])
-            if rank == 0:
+            if rank == 0 and world > 1:   # one GPU: the render kernel wrote the 8-bit image itself
                 renderers[k].resolve()
             in_flight[k], pending[k] = False, None
 

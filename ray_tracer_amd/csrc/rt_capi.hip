@@ -88,7 +88,7 @@ struct rt_ctx {
   // tile scheduling of the megakernels: cost measured by the last launch, order for the next
   uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
   uint32_t tiles_x = 0, n_tiles = 0;
-  bool order_valid = false, use_tile_order = true;
+  bool order_valid = false, use_tile_order = true, use_probe = true;
   // the order is refreshed after launches 1, 2, 4, 8, then every 16th since the last change
   // of scene or parameters; in between the costs keep accumulating (atomicMax)
   uint32_t order_interval = 1, launches_since_order = 0;
@@ -245,6 +245,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
   if ((e = hipMemsetAsync(c->d_tile_cost, 0, c->n_tiles * sizeof(uint32_t), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(tile cost)");
   if (const char *env = std::getenv("RT_TILE_ORDER")) c->use_tile_order = env[0] != '0';
+  if (const char *env = std::getenv("RT_TILE_PROBE")) c->use_probe = env[0] != '0';
   int rc = rt_clear(c);
   if (rc != RT_OK) {
     rt_destroy(c);
@@ -562,7 +563,7 @@ int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame
   std::string err;
   const bool tile_kernels = c->mode == RT_MODE_MEGAKERNEL && !degenerate &&
                             !((c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->use_bvh && !strict);
-  if (he == hipSuccess && tile_kernels && c->use_tile_order && !c->order_valid &&
+  if (he == hipSuccess && tile_kernels && c->use_tile_order && c->use_probe && !c->order_valid &&
       (uint64_t)c->P.n_spp * n_frames >= 32u) {
     // First launch of the context: no costs measured yet.  Two samples per pixel of the first
     // frame, traced without writing anything but the per-tile costs, are enough to tell the

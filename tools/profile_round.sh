@@ -6,6 +6,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err || exit 1
+export RT_TILE_PROBE=0   # counter passes: no probe launch among the dispatches that are averaged
 for size in 1920x1080 3840x2160; do
   timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_$size/fetch -- python3 $root/tools/prof_render.py megakernel default 8 $size > /dev/null 2>> $out/pmc.err || exit 1
   timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_$size/write -- python3 $root/tools/prof_render.py megakernel default 8 $size > /dev/null 2>> $out/pmc.err || exit 1
