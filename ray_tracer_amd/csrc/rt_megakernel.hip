@@ -17,8 +17,11 @@
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 1
 #endif
+#ifndef RT_REGEN_SHADE_BATCH
+#define RT_REGEN_SHADE_BATCH 48  // hits a wave gathers before it runs the surface code (1: none; 3840x2160: 1 4.36, 12 4.18, 28 4.08, 48 4.03 ms)
+#endif
 #ifndef RT_REGEN_END_BATCH
-#define RT_REGEN_END_BATCH 8   // ended paths a wave gathers before it runs the path-end code
+#define RT_REGEN_END_BATCH 24  // ended paths a wave gathers before it runs the path-end code (8 and 24 within 1 % once hits are gathered too)
 #endif
 #ifndef RT_SCHED_WAVES
 #define RT_SCHED_WAVES 5  // waves per SIMD the untextured fast k_mega_sched is compiled for (96 VGPR; 10k spheres at 3840x2160: 5.68 against 5.90 ms)
@@ -134,6 +137,37 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
   }
 }
 
+// Path-end code of k_mega_regen's batched loops, for the lanes whose path has ended: light of
+// the environment for a path that escaped, sample sum, frame epilogue, next primary ray.
+// (A macro over the kernel's locals rather than a lambda: with a lambda the batched kernel,
+// which is compiled against a register cap, came out 4 % slower.)
+#define RT_END_PATHS() \
+        if (active && ended != 0) { \
+          if (ended == 1) light = fma3v(environment<STRICT>(P, d), colour, light); \
+          ended = 0; \
+          total = total + light; \
+          ++s; \
+          if (s >= P.n_spp) { \
+            frame_epilogue(P, total, (float)frame, O.linear_accum, acc, img); \
+            ++fi; \
+            if (fi >= F.count) { \
+              active = false; \
+            } else { \
+              frame += F.stride; \
+              rng = pixel_seed(P, px, py, frame); \
+              total = mk3(0.f, 0.f, 0.f); \
+              s = 0; \
+            } \
+          } \
+          if (active) { \
+            sample_ray<STRICT>(P, base, rng, o, d); \
+            light = mk3(0.f, 0.f, 0.f); \
+            colour = mk3(1.f, 1.f, 1.f); \
+            b = 0; \
+            skip = -1; \
+          } \
+        }
+
 // Requires n_spp >= 1 and n_bounce >= 1 (the host routes other cases to k_mega_nested).
 // FORM: which of the two loops below the blocks run: kRegenPlain, kRegenBatched, or
 // kRegenMixed = the plain loop for the first O.chain_ranks blocks of an ordered launch (the
@@ -151,6 +185,11 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
   // sphere's centre to the shading code instead of having it fetched again.
   constexpr bool CHAIN = !BVH;
+  // batch sizes of the batched loop: large where the whole launch runs it, small where it
+  // shares the launch with the plain loop (tiles just below the chain ranks still have long
+  // chains, which large batches stretch: 1920x1080 mixed 1.27 against 1.32 ms)
+  constexpr int SHADE_BATCH = FORM == kRegenBatched ? RT_REGEN_SHADE_BATCH : 1;
+  constexpr int END_BATCH = FORM == kRegenBatched ? RT_REGEN_END_BATCH : 8;
   constexpr int BLOCK = BVH ? 256 : kTileBlock;
   const uint32_t rank = tile_rank<BLOCK>(), tile_t = tile_thread<BLOCK>();
   const bool batched = FORM == kRegenMixed ? rank >= O.chain_ranks : FORM == kRegenBatched;
@@ -181,55 +220,70 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
     if (batched) {
       // Throughput form, for launches with many more tiles than the device holds at once.
       // A path that ended (missed everything, or reached the bounce limit) waits until
-      // RT_REGEN_END_BATCH lanes of the wave have one to end, or until no lane can trace;
-      // the path-end code (environment, sample sum, next primary ray) then runs for all of
-      // them at once instead of in every iteration for the two or three lanes that happen to
-      // need it.  10 % more segments per second at 3840x2160.  It does not shorten the wave
-      // that bounds a small launch (its lanes now also wait for the batch), which is why the
-      // plain loop below stays for those.
+      // END_BATCH lanes of the wave have one to end; the path-end code (environment, sample
+      // sum, next primary ray) then runs for all of them at once instead of in every
+      // iteration for the two or three lanes that happen to need it.  It does not shorten the
+      // wave that bounds a small launch (its lanes now also wait for the batch), which is why
+      // the plain loop below stays for those.
       bool active = true;
       int ended = 0;  // 0: tracing, 1: missed (environment still to add), 2: bounce limit
-      while (true) {
-        if (active && ended == 0) {
-          Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
-          ++nrays;
-          if (s == 0 && b == 0) id0 = h.idx;
-          if (h.idx >= 0) {
-            skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
-            ++b;
-            if (b >= P.n_bounce) ended = 2;
-          } else {
-            ended = 1;
-          }
-        }
-        const int n_ended = __builtin_popcountll(__ballot(active && ended != 0));
-        const int n_tracing = __builtin_popcountll(__ballot(active && ended == 0));
-        if (n_ended + n_tracing == 0) break;
-        if (n_ended < RT_REGEN_END_BATCH && n_tracing != 0) continue;
-        if (active && ended != 0) {
-          if (ended == 1) light = fma3v(environment<STRICT>(P, d), colour, light);
-          ended = 0;
-          total = total + light;
-          ++s;
-          if (s >= P.n_spp) {
-            frame_epilogue(P, total, (float)frame, O.linear_accum, acc, img);
-            ++fi;
-            if (fi >= F.count) {
-              active = false;
+      if constexpr (SHADE_BATCH > 1) {
+        // Hits wait too: the surface code runs once SHADE_BATCH lanes have one pending,
+        // instead of after every search for the third of the lanes that hit.
+        Hit pending;
+        pending.idx = -1;
+        pending.dst = 0.0f;
+        pending.cx = pending.cy = pending.cz = 0.0f;
+        bool has_hit = false;
+        while (true) {
+          if (active && ended == 0 && !has_hit) {
+            const Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
+            ++nrays;
+            if (s == 0 && b == 0) id0 = h.idx;
+            if (h.idx >= 0) {
+              pending = h;
+              has_hit = true;
             } else {
-              frame += F.stride;
-              rng = pixel_seed(P, px, py, frame);
-              total = mk3(0.f, 0.f, 0.f);
-              s = 0;
+              ended = 1;
             }
           }
-          if (active) {
-            sample_ray<STRICT>(P, base, rng, o, d);
-            light = mk3(0.f, 0.f, 0.f);
-            colour = mk3(1.f, 1.f, 1.f);
-            b = 0;
-            skip = -1;
+          // every lane that could trace has; now at least one of the other two steps must
+          // run: those that have their batch together, else the one more lanes wait for
+          const int n_hit = __builtin_popcountll(__ballot(has_hit));
+          const int n_ended = __builtin_popcountll(__ballot(active && ended != 0));
+          if (n_hit + n_ended == 0) break;
+          bool run_shade = n_hit >= SHADE_BATCH, run_end = n_ended >= END_BATCH;
+          if (!run_shade && !run_end) {
+            run_shade = n_hit >= n_ended;
+            run_end = !run_shade;
           }
+          if (run_shade && has_hit) {
+            skip = shade_hit<STRICT, TEX, APPROX>(S, pending, rng, o, d, light, colour);
+            has_hit = false;
+            ++b;
+            if (b >= P.n_bounce) ended = 2;
+          }
+          if (!run_end) continue;
+          RT_END_PATHS();
+        }
+      } else {
+        while (true) {
+          if (active && ended == 0) {
+            const Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
+            ++nrays;
+            if (s == 0 && b == 0) id0 = h.idx;
+            if (h.idx >= 0) {
+              skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
+              ++b;
+              if (b >= P.n_bounce) ended = 2;
+            } else {
+              ended = 1;
+            }
+          }
+          const int n_ended = __builtin_popcountll(__ballot(active && ended != 0));
+          const int n_tracing = __builtin_popcountll(__ballot(active && ended == 0));
+          if (n_ended + n_tracing == 0) break;
+          if (n_ended >= END_BATCH || n_tracing == 0) RT_END_PATHS();
         }
       }
     } else {
@@ -476,8 +530,8 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
   else {
     // Brute-force scenes.  Many tiles: throughput is everything, the batched loop.  Fewer: the
     // longest chain sets the time; with a measured order its tiles (and only they) get the
-    // plain loop, without one every tile does.  1920x1080: plain 1.40, batched 1.39, mixed
-    // 1.27 ms; 3840x2160: 5.07, 4.48, 4.60 (the mixed kernel holds both loops' registers).
+    // plain loop, without one every tile does.  1920x1080: plain 1.36, batched 1.61, mixed
+    // 1.27 ms; 3840x2160: 5.00, 4.02, 4.35 (the mixed kernel holds both loops' registers).
     int form = O.n_tiles >= batch_tiles ? kRegenBatched : (O.tile_order ? kRegenMixed : kRegenPlain);
     if (forced_form >= 0 && (forced_form != kRegenMixed || O.tile_order)) form = forced_form;
     Outputs Q = O;
