@@ -26,6 +26,9 @@
 #ifndef RT_SCHED_WAVES
 #define RT_SCHED_WAVES 5  // waves per SIMD the untextured fast k_mega_sched is compiled for (96 VGPR; 10k spheres at 3840x2160: 5.68 against 5.90 ms)
 #endif
+#ifndef RT_REGEN_BATCHED_TEX_WAVES
+#define RT_REGEN_BATCHED_TEX_WAVES 6  // the textured batched loop (80 VGPR; 8K frame pair 30.1 ms, uncapped 32.3, 7 waves 31.3)
+#endif
 #ifndef RT_REGEN_BATCHED_WAVES
 #define RT_REGEN_BATCHED_WAVES 7  // waves per SIMD the untextured batched loop is compiled for (72 VGPR; 6: +2 %, 8: +4 % time at 3840x2160)
 #endif
@@ -176,7 +179,8 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
 constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
 // waves per SIMD a form is compiled for (the register budget follows from it)
 constexpr int regen_waves(bool strict, bool tex, int form) {
-  return form == kRegenBatched && !tex && !strict ? RT_REGEN_BATCHED_WAVES : RT_MEGA_WAVES;
+  if (form != kRegenBatched || strict) return RT_MEGA_WAVES;
+  return tex ? RT_REGEN_BATCHED_TEX_WAVES : RT_REGEN_BATCHED_WAVES;
 }
 template <bool STRICT, bool BVH, bool TEX, bool APPROX, int FORM>
 __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {

@@ -842,6 +842,11 @@ def test_regen_loop_forms_are_bit_identical():
         "    r.sync()\n"
         "    m = hashlib.sha256()\n"
         "    m.update(r.read_accum().tobytes()); m.update(r.read_rgba8().tobytes()); m.update(r.read_primary_ids().tobytes())\n"
+        "    r.set_texture(rt.brick_texture(64, 64), 2, 1, rt.TEX_MAP_PLANAR_XZ, (0.25, 0.25))\n"
+        "    for f in range(4, 7):\n"
+        "        r.render(f, 1, 1)\n"
+        "    r.sync()\n"
+        "    m.update(r.read_accum().tobytes()); m.update(r.read_rgba8().tobytes())\n"
         "    print('DIGEST', m.hexdigest(), r.stats().rays)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
