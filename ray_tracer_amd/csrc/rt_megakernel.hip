@@ -24,7 +24,7 @@
 #define RT_REGEN_END_BATCH 24  // ended paths a wave gathers before it runs the path-end code (8 and 24 within 1 % once hits are gathered too)
 #endif
 #ifndef RT_SCHED_WAVES
-#define RT_SCHED_WAVES 5  // waves per SIMD the untextured fast k_mega_sched is compiled for (96 VGPR; 10k spheres at 3840x2160: 5.68 against 5.90 ms)
+#define RT_SCHED_WAVES 5  // waves per SIMD the untextured fast k_mega_sched is compiled for (at most 96 VGPR; its LDS stack allows five)
 #endif
 #ifndef RT_REGEN_BATCHED_TEX_WAVES
 #define RT_REGEN_BATCHED_TEX_WAVES 6  // the textured batched loop (80 VGPR; 8K frame pair 30.1 ms, uncapped 32.3, 7 waves 31.3)
