@@ -153,6 +153,7 @@ rt::Scene scene_view(const rt_ctx *c) {
     S.large_geom = c->bvh.large_geom;
     S.large_prim = c->bvh.large_prim;
     S.n_large = c->bvh.n_large;
+    S.stack_entries = std::max(c->bvh.height, 1u);
   }
   return S;
 }

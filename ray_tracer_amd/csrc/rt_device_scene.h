@@ -72,6 +72,7 @@ struct Scene {
   const float4 *large_geom;     // oversized spheres, tested before the tree
   const uint32_t *large_prim;
   uint32_t n_large;
+  uint32_t stack_entries;       // traversal stack entries a search can need (tree height, at most kBvhStackEntries)
   const Texture *tex;       // device copy of the texture binding; null: none (kept behind a
                             // pointer so untextured launches carry two scalar registers for it)
 };

@@ -24,7 +24,7 @@
 #define RT_REGEN_END_BATCH 24  // ended paths a wave gathers before it runs the path-end code (8 and 24 within 1 % once hits are gathered too)
 #endif
 #ifndef RT_SCHED_WAVES
-#define RT_SCHED_WAVES 5  // waves per SIMD the untextured fast k_mega_sched is compiled for (at most 96 VGPR; its LDS stack allows five)
+#define RT_SCHED_WAVES 6  // waves per SIMD the untextured fast k_mega_sched is compiled for (80 VGPR; 3840x2160, 10k spheres / terrain: 5 waves 5.42 / 14.65 ms, 6: 5.35 / 14.52, 7: 5.37 / 14.89)
 #endif
 #ifndef RT_REGEN_BATCHED_TEX_WAVES
 #define RT_REGEN_BATCHED_TEX_WAVES 6  // the textured batched loop (80 VGPR; 8K frame pair 30.1 ms, uncapped 32.3, 7 waves 31.3)
@@ -399,7 +399,9 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
 
 template <bool STRICT, bool TEX, bool APPROX>
 __global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
-  __shared__ int stack[kBvhStack * kTileBlock];
+  // [entry][thread], S.stack_entries entries: the launch sizes it by the height of the tree
+  // (a 16-level tree leaves room for twice the waves a fixed 32-entry stack would)
+  extern __shared__ int stack[];
   const uint32_t tile = ordered_tile(O, tile_rank<kTileBlock>());
   uint32_t px, py;
   pixel_of_tile(tile, O.tiles_x, tile_thread<kTileBlock>(), px, py);
@@ -533,7 +535,8 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
   if (nested)
     hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX, APPROX>), grid, block, 0, stream, P, S, F, O);
   else if (BVH && sched)
-    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX, APPROX>), wave_tiles, wave_block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX, APPROX>), wave_tiles, wave_block,
+                       (size_t)S.stack_entries * kTileBlock * sizeof(int), stream, P, S, F, O);
   else if (BVH)
     hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, O);
   else {
