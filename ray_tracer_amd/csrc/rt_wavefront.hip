@@ -38,6 +38,10 @@
 #include "rt_shading.h"
 #include "rt_traverse.h"
 
+#ifndef RT_WF_TREE_WAVES
+#define RT_WF_TREE_WAVES 1  // waves per SIMD the scheduled tree kernels are compiled for
+#endif
+
 namespace rt {
 
 struct WfView {
@@ -176,10 +180,10 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
 // wave-scheduled loop (see rt_traverse.h): inner and leaf steps as in k_mega_sched, and a
 // "next" step that stores the finished search and starts the thread's next live pixel.
 template <bool APPROX>
-__global__ __launch_bounds__(256) void k_wf_extend_tree(Scene S, WfView V, uint32_t slot,
+__global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene S, WfView V, uint32_t slot,
                                                         uint32_t n_pixels, int32_t *ids) {
   __shared__ uint32_t lds[kWfETree * 4 + 1];
-  __shared__ int stack[kBvhStack * kBlockThreads];
+  extern __shared__ int stack[];  // [entry][thread], S.stack_entries entries (sized by the launch)
   uint32_t *cnt = V.counts + 4u * (slot & 3u);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     uint32_t *z = V.counts + 4u * ((slot + 1u) & 3u);
@@ -422,9 +426,9 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
 // The drain launch for LBVH scenes: the same resumption, in k_mega_sched's wave-scheduled
 // form (inner / leaf / shade steps chosen by waiting-lane count).
 template <bool STRICT, bool TEX, bool APPROX>
-__global__ __launch_bounds__(256) void k_wf_drain_tree(Params P, Scene S, WfView V, uint32_t frame,
+__global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params P, Scene S, WfView V, uint32_t frame,
                                                        Outputs O) {
-  __shared__ int stack[kBvhStack * kBlockThreads];
+  extern __shared__ int stack[];  // [entry][thread], S.stack_entries entries (sized by the launch)
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
   uint32_t nrays = 0;
@@ -590,6 +594,8 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
   constexpr int E = BVH ? kWfETree : kWfEBrute;
   const uint32_t window_blocks = (n + 256u * E - 1u) / (256u * E);
   const uint32_t compact_blocks = (n + kWfChunk - 1u) / kWfChunk;
+  // LDS of the scheduled tree kernels: one traversal stack per thread, as deep as the tree
+  const size_t tree_stack_bytes = (size_t)(S.stack_entries ? S.stack_entries : 1u) * 256u * sizeof(int);
   WF_HIP(hipMemsetAsync(V.counts, 0, 128, stream));
   hipLaunchKernelGGL((k_wf_init<STRICT>), dim3(full_blocks), dim3(256), 0, stream, P, frame, V);
   ++*launches;
@@ -603,7 +609,7 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
     if (bound <= drain_threshold) {
       hipLaunchKernelGGL(k_wf_compact, dim3(compact_blocks), dim3(256), 0, stream, V, n);
       if constexpr (BVH)
-        hipLaunchKernelGGL((k_wf_drain_tree<STRICT, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0,
+        hipLaunchKernelGGL((k_wf_drain_tree<STRICT, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), tree_stack_bytes,
                            stream, P, S, V, frame, O);
       else
         hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0,
@@ -612,7 +618,7 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
       break;
     }
     if constexpr (BVH)
-      hipLaunchKernelGGL((k_wf_extend_tree<APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+      hipLaunchKernelGGL((k_wf_extend_tree<APPROX>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
                          O.ids);
     else
       hipLaunchKernelGGL((k_wf_extend<BVH, APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
