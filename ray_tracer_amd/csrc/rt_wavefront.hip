@@ -389,12 +389,14 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
     int id0 = -2;
     int skip = __float_as_int(p2.w);
     while (true) {
-      const Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
+      // the drain is the chain of the slowest pixels: the brute-force search in its form for a
+      // wave running alone, the sphere's centre carried with the hit (as k_mega_regen's plain loop)
+      const Hit h = closest_hit<BVH, APPROX, !BVH>(S, o, d, stack, skip);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, TEX, APPROX, !BVH>(S, h, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
