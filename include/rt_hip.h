@@ -132,6 +132,21 @@ typedef struct rt_texture_desc {
 } rt_texture_desc;
 int rt_set_texture(rt_ctx *ctx, const rt_texture_desc *desc, const void *rgba8);
 
+/* No counterpart in the reference, whose material (ray_tracing.comp:13-20) has no refraction
+ * term and whose sphere test returns the near root only (:157-161), so a ray inside a sphere
+ * never hits it: dielectric spheres.  ior = count floats, count == the number of spheres last
+ * given to rt_set_spheres; ior[i] > 0 makes sphere i a dielectric with that index of
+ * refraction, anything else leaves it with the reference's material model.  A hit on a
+ * dielectric sphere draws ONE random number and reflects or refracts (Snell's law, Schlick's
+ * reflectance; total internal reflection when there is no refracted ray); the throughput is
+ * multiplied by colour.rgb either way and emission is added as for any other hit.  A ray that
+ * was refracted into a sphere hits THAT sphere at its far root until it leaves it again; all
+ * other spheres keep the reference's near-root test.  The 48-byte material has no spare
+ * field, hence this side table.  ior == NULL or count == 0 removes it; rt_set_spheres removes
+ * it too (the indices belong to the sphere set).  A bound texture is not sampled on dielectric
+ * spheres. */
+int rt_set_dielectric(rt_ctx *ctx, const float *ior, uint32_t count);
+
 /* Replaces bind pipeline + descriptor sets + vkCmdDispatch(W/16,H/16,1) + submit,
  * main.cpp:819-868, for n_frames dispatches with ubo.frame.x = first_frame,
  * first_frame + frame_stride, ...  (main.cpp:1028 increments it by one per

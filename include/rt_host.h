@@ -61,6 +61,13 @@ uint32_t rt_default_scene(rt_sphere out3[3]);
  * material has no refraction term, so there is no dielectric class.  Returns n. */
 uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out);
 
+/* The same scene (same seed, same draws, same centres and radii) with the third material
+ * class made of glass instead of a glossy coat: for those spheres ior_out[i] = 1.5 and
+ * colour.rgb = 0.75 + 0.25 * (the drawn r, g, b) is the tint; every other sphere gets
+ * ior_out[i] = 0 and the record rt_grid_scene writes.  ior_out (n floats) is what
+ * rt_set_dielectric takes.  Returns n. */
+uint32_t rt_grid_scene_glass(uint32_t n, uint32_t seed, rt_sphere *out, float *ior_out);
+
 /* No counterpart in the reference, whose only texture is a photograph
  * (assets/textures/brickwall.jpg, never sampled): a deterministic brick-wall pattern for
  * tests and benchmarks.  width x height sRGB texels, 4 bytes each, written row by row.

@@ -137,8 +137,44 @@ int rto_render_scene(const void *ubo272, const void *spheres64, uint32_t n_spher
                      int math_mode, int accum_mode, float *accum, uint8_t *rgba8, int32_t *ids,
                      uint64_t *rays, int threads);
 
+/* Everything above in one call, plus two more options.
+ *   ior      EXTENSION (the reference has no refraction, ray_tracing.comp:13-20,157-161):
+ *            optional array of n_spheres floats; ior[i] > 0 makes sphere i a dielectric with
+ *            that index of refraction.  Rule: dielectric_scatter() and closest_hit() in
+ *            rt_oracle.c (Snell + Schlick, one random draw; a ray refracted into a sphere hits
+ *            that sphere at its far root).
+ *   pixels   optional list of n_pixels pixel indices (y * width + x).  Only those pixels are
+ *            shaded -- each exactly as in a whole-image render, since pixels are independent
+ *            (ray_tracing.comp:80-82) -- and accum / rgba8 / ids are then COMPACT arrays
+ *            with one entry per listed pixel, in list order.  Lets a test check a sample of a
+ *            scene whose full brute-force render would take hours on a CPU. */
+typedef struct rto_job {
+  const void *ubo272;
+  const void *spheres64;
+  uint32_t n_spheres;
+  const rto_mesh *mesh;
+  const rto_texture *texture;
+  const float *ior;
+  uint32_t width, height, first_frame, n_frames, frame_stride;
+  int math_mode, accum_mode;
+  const uint32_t *pixels;
+  uint32_t n_pixels;
+  float *accum;
+  uint8_t *rgba8;
+  int32_t *ids;
+  uint64_t *rays;
+  int threads;
+} rto_job;
+int rto_render_job(const rto_job *job);
+
 /* one bilinear sample of the texture at (u, v), for unit tests of the sampling rule */
 void rto_texture_sample(const rto_texture *texture, float u, float v, float out_rgb[3]);
+
+/* one dielectric scatter (see dielectric_scatter() in rt_oracle.c), for unit tests of the rule:
+ * the outward unit normal of the sphere at the hit, exiting != 0 when the ray travels inside
+ * it; advances *rng by one draw */
+void rto_dielectric_scatter(const float dir[3], const float normal[3], float ior, int exiting,
+                            uint32_t *rng, float out_dir[3], int *out_refracted);
 
 /* byte -> linear float of the sRGB transfer function (IEC 61966-2-1), evaluated in double */
 float rto_srgb_to_linear(uint8_t v);

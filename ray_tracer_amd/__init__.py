@@ -33,12 +33,12 @@ from ._capi import (  # noqa: F401
     write_png,
     write_ppm,
 )
-from .scenes import grid_spheres_scene, make_ubo, matte, terrain_mesh  # noqa: F401
+from .scenes import grid_spheres_scene, grid_spheres_scene_glass, make_ubo, matte, terrain_mesh  # noqa: F401
 
 __all__ = [
     "LIB_PATH", "MODE_MEGAKERNEL", "MODE_MEGAKERNEL_NESTED", "MODE_WAVEFRONT",
     "FLAG_ACCUM_LINEAR", "FLAG_COUNT_TRAVERSAL", "FLAG_FORCE_BRUTE", "FLAG_FORCE_BVH", "FLAG_STRICT_MATH",
     "Camera", "Renderer", "RtError", "Stats", "debug_eval", "default_scene", "default_ubo",
     "TEX_MAP_OCTAHEDRAL", "TEX_MAP_PLANAR_XZ", "brick_texture",
-    "decode_jpeg", "load_obj", "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "make_ubo", "matte", "terrain_mesh",
+    "decode_jpeg", "load_obj", "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "grid_spheres_scene_glass", "make_ubo", "matte", "terrain_mesh",
 ]

@@ -119,6 +119,7 @@ lib.rt_set_params.argtypes = [C.c_void_p, C.c_void_p]
 lib.rt_set_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 lib.rt_set_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
 lib.rt_set_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+lib.rt_set_dielectric.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 lib.rt_brick_texture.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
 lib.rt_brick_texture.restype = None
 lib.rt_ingest_error.restype = C.c_char_p
@@ -302,6 +303,14 @@ class Renderer:
         d = _TextureDesc(C.sizeof(_TextureDesc), t.shape[1], t.shape[0], TEX_SRGB if srgb else 0,
                          mapping, float(scale[0]), float(scale[1]), first_prim, n_prims)
         _check(lib.rt_set_texture(self._ctx, C.byref(d), t.ctypes.data_as(C.c_void_p)))
+
+    def set_dielectric(self, ior: Optional[np.ndarray]) -> None:
+        """ior (n_spheres,) float32: > 0 makes that sphere a dielectric; None removes the table."""
+        if ior is None:
+            _check(lib.rt_set_dielectric(self._ctx, None, 0))
+            return
+        v = np.ascontiguousarray(ior, dtype=np.float32).reshape(-1)
+        _check(lib.rt_set_dielectric(self._ctx, v.ctypes.data_as(C.c_void_p), v.size))
 
     def render(self, first_frame: int = 0, n_frames: int = 1, stride: int = 1) -> None:
         _check(lib.rt_render(self._ctx, first_frame, n_frames, stride))

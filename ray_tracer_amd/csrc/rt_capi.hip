@@ -69,6 +69,9 @@ struct rt_ctx {
   float mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0};  // bounds of the mesh vertices
   float mesh_material[12] = {0};
 
+  float *d_ior = nullptr;        // per sphere, > 0: dielectric (optional; null: none)
+  bool have_ior = false;
+
   uchar4 *d_texels = nullptr;    // albedo texture (optional)
   float *d_tex_lut = nullptr;    // byte -> linear value
   rt::Texture *d_tex = nullptr;  // device copy of the binding
@@ -146,6 +149,7 @@ rt::Scene scene_view(const rt_ctx *c) {
   S.tri = c->d_tri;
   S.n_tris = c->n_tris;
   S.tex = c->have_tex ? c->d_tex : nullptr;
+  S.ior = c->have_ior ? c->d_ior : nullptr;
   if (c->use_bvh) {
     S.nodes = c->bvh.nodes;
     S.sorted_prim = c->bvh.sorted_prim;
@@ -269,6 +273,7 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_geom) hipFree(c->d_geom);
   if (c->d_material) hipFree(c->d_material);
   if (c->d_tri) hipFree(c->d_tri);
+  if (c->d_ior) hipFree(c->d_ior);
   if (c->d_texels) hipFree(c->d_texels);
   if (c->d_tex_lut) hipFree(c->d_tex_lut);
   if (c->d_tex) hipFree(c->d_tex);
@@ -360,6 +365,7 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
   c->have_scene = false;
   c->use_bvh = false;
   c->n_spheres = 0;
+  c->have_ior = false;  // indices of refraction belong to the sphere set they were given for
   if (c->d_geom) RT_HIP(hipFree(c->d_geom));
   c->d_geom = nullptr;
   if (c->d_material) RT_HIP(hipFree(c->d_material));
@@ -475,6 +481,31 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
   int rc = rebuild_accel(c);
   if (rc != RT_OK) return rc;
   c->have_scene = true;
+  return RT_OK;
+}
+
+int rt_set_dielectric(rt_ctx *c, const float *ior, uint32_t count) {
+  if (!c) return fail(RT_ERR_INVALID, "rt_set_dielectric: null context");
+  RT_HIP(hipSetDevice(c->device));
+  RT_HIP(hipStreamSynchronize(c->stream));  // launches in flight may still read the old table
+  c->have_ior = false;
+  if (!ior || count == 0) return RT_OK;
+  if (count != c->n_spheres)
+    return fail(RT_ERR_INVALID, "rt_set_dielectric: %u values for %u spheres", count, c->n_spheres);
+  bool any = false;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (ior[i] != ior[i] || ior[i] > 1.0e6f)
+      return fail(RT_ERR_INVALID, "rt_set_dielectric: index of refraction %g for sphere %u", (double)ior[i], i);
+    any = any || ior[i] > 0.0f;
+  }
+  if (!any) return RT_OK;
+  if (c->d_ior) RT_HIP(hipFree(c->d_ior));
+  c->d_ior = nullptr;
+  RT_HIP(hipMalloc(&c->d_ior, (size_t)count * sizeof(float)));
+  RT_HIP(hipMemcpy(c->d_ior, ior, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+  c->have_ior = true;
+  c->order_interval = 1;
+  c->launches_since_order = 0;
   return RT_OK;
 }
 

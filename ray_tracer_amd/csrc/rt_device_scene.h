@@ -75,6 +75,8 @@ struct Scene {
   uint32_t stack_entries;       // traversal stack entries a search can need (tree height, at most kBvhStackEntries)
   const Texture *tex;       // device copy of the texture binding; null: none (kept behind a
                             // pointer so untextured launches carry two scalar registers for it)
+  const float *ior;         // per sphere: index of refraction of a dielectric sphere, <= 0 for the
+                            // reference's material; null: no dielectric spheres
 };
 
 struct FrameSeq {

@@ -234,8 +234,19 @@ void rt_brick_texture(uint32_t width, uint32_t height, uint8_t *out) {
   }
 }
 
-uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out) {
+static uint32_t grid_scene(uint32_t n, uint32_t seed, rt_sphere *out, float *ior_out);
+
+uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out) { return grid_scene(n, seed, out, nullptr); }
+
+uint32_t rt_grid_scene_glass(uint32_t n, uint32_t seed, rt_sphere *out, float *ior_out) {
+  if (!ior_out) return 0;
+  return grid_scene(n, seed, out, ior_out);
+}
+
+// ior_out == null: the third material class is the glossy coat; else glass (see rt_host.h)
+static uint32_t grid_scene(uint32_t n, uint32_t seed, rt_sphere *out, float *ior_out) {
   if (!out || n == 0) return 0;
+  if (ior_out) std::memset(ior_out, 0, (size_t)n * sizeof(float));
   uint32_t state = seed;
   auto draw = [&state]() -> float {  // the shader's nextRandom / randomValue
     state = state * 747796405u + 2891336453u;
@@ -283,6 +294,12 @@ uint32_t rt_grid_scene(uint32_t n, uint32_t seed, rt_sphere *out) {
       s.material.specular_colour[0] = s.material.specular_colour[1] = 1.0f;
       s.material.specular_colour[2] = 1.0f;
       s.material.specular_colour[3] = 0.15f + 0.35f * draw();
+      if (ior_out) {
+        ior_out[i] = 1.5f;
+        s.material.colour[0] = 0.75f + 0.25f * cr;
+        s.material.colour[1] = 0.75f + 0.25f * cg;
+        s.material.colour[2] = 0.75f + 0.25f * cb;
+      }
     }
     if (i % 50 == 0) {
       s.material.emission_colour[0] = cr; s.material.emission_colour[1] = cg;

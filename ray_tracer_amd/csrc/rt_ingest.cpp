@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+
 namespace {
 
 thread_local std::string g_ingest_error;
@@ -21,17 +23,25 @@ int ingest_fail(const char *msg) {
   return -1;
 }
 
+// regular files of at most 4 GiB (a directory opens with fopen and reports a size of LONG_MAX)
 bool read_file(const char *path, std::vector<uint8_t> &out) {
+  struct stat st;
+  if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return false;
   FILE *f = std::fopen(path, "rb");
   if (!f) return false;
   std::fseek(f, 0, SEEK_END);
   long n = std::ftell(f);
   std::fseek(f, 0, SEEK_SET);
-  if (n < 0) {
+  if (n < 0 || (unsigned long long)n > (4ull << 30)) {
     std::fclose(f);
     return false;
   }
-  out.resize((size_t)n);
+  try {
+    out.resize((size_t)n);
+  } catch (...) {
+    std::fclose(f);
+    return false;
+  }
   size_t got = n ? std::fread(out.data(), 1, (size_t)n, f) : 0;
   std::fclose(f);
   return got == (size_t)n;
@@ -85,9 +95,24 @@ struct Decoder {
   int bit_count = 0;
   bool hit_marker = false;
 
+  // header reads stop at `limit` (the end of the current segment, or of the file): a read past
+  // it returns 0 and sets `overrun`, which the segment loop turns into an error
+  size_t limit = 0;
+  bool overrun = false;
+
   bool need(size_t n) const { return pos + n <= size; }
-  int u8() { return data[pos++]; }
+  int u8() {
+    if (pos + 1 > limit) {
+      overrun = true;
+      return 0;
+    }
+    return data[pos++];
+  }
   int u16() {
+    if (pos + 2 > limit) {
+      overrun = true;
+      return 0;
+    }
     int v = (data[pos] << 8) | data[pos + 1];
     pos += 2;
     return v;
@@ -359,6 +384,7 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
   D.pos = 2;
   bool decoded = false;
   while (!decoded) {
+    D.limit = D.size;
     if (!D.need(4)) return ingest_fail("jpeg: truncated before the scan");
     if (D.data[D.pos] != 0xFF) return ingest_fail("jpeg: marker expected");
     while (D.pos < D.size && D.data[D.pos] == 0xFF) ++D.pos;  // fill bytes
@@ -368,13 +394,17 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
     const int len = D.u16();
     if (len < 2 || !D.need((size_t)len - 2)) return ingest_fail("jpeg: bad segment length");
     const size_t end = D.pos + (size_t)len - 2;
+    D.limit = end;  // the handlers below read fixed-size fields: none may leave the segment
     switch (marker) {
       case 0xDB:  // DQT
         while (D.pos < end) {
           const int pq_tq = D.u8();
           const int precision = pq_tq >> 4, t = pq_tq & 15;
           if (t > 3) return ingest_fail("jpeg: bad quantisation table id");
-          for (int k = 0; k < 64; ++k) D.quant[t][k] = (uint16_t)(precision ? D.u16() : D.u8());
+          uint16_t table[64];
+          for (int k = 0; k < 64; ++k) table[k] = (uint16_t)(precision ? D.u16() : D.u8());
+          if (D.overrun) return ingest_fail("jpeg: quantisation table runs past its segment");
+          std::memcpy(D.quant[t], table, sizeof table);
           D.have_quant[t] = true;
         }
         break;
@@ -384,6 +414,10 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
         D.height = D.u16();
         D.width = D.u16();
         D.n_comp = D.u8();
+        if (D.overrun) {
+          D.n_comp = 0;
+          return ingest_fail("jpeg: frame header runs past its segment");
+        }
         if (D.width <= 0 || D.height <= 0 || D.width > 32768 || D.height > 32768 ||
             (long long)D.width * D.height > (1ll << 26))
           return ingest_fail("jpeg: bad image size (at most 2^26 pixels)");
@@ -397,6 +431,7 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
           if (D.comp[c].h < 1 || D.comp[c].h > 2 || D.comp[c].v < 1 || D.comp[c].v > 2 || D.comp[c].tq > 3)
             return ingest_fail("jpeg: unsupported sampling factors");
         }
+        if (D.overrun) return ingest_fail("jpeg: frame header runs past its segment");
         break;
       }
       case 0xC2:
@@ -412,13 +447,14 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
             counts[k] = (uint8_t)D.u8();
             total += counts[k];
           }
-          if (total > 256 || D.pos + (size_t)total > end) return ingest_fail("jpeg: bad Huffman table");
+          if (D.overrun || total > 256 || D.pos + (size_t)total > end) return ingest_fail("jpeg: bad Huffman table");
           build_huffman(cls ? D.ac[t] : D.dc[t], counts, D.data + D.pos, total);
           D.pos += (size_t)total;
         }
         break;
       case 0xDD:  // DRI
         D.restart_interval = D.u16();
+        if (D.overrun) return ingest_fail("jpeg: restart interval runs past its segment");
         break;
       case 0xDA: {  // SOS
         if (!D.n_comp) return ingest_fail("jpeg: scan before frame header");
@@ -433,6 +469,7 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
           D.comp[c].ta = tables & 15;
           if (D.comp[c].td > 3 || D.comp[c].ta > 3) return ingest_fail("jpeg: bad table selector");
         }
+        if (D.overrun) return ingest_fail("jpeg: scan header runs past its segment");
         D.pos = end;
         if (decode_scan(D) != 0) return -1;
         decoded = true;

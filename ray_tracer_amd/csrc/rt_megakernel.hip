@@ -43,8 +43,9 @@ namespace rt {
 
 // COUNT (only with BVH): also tallies LBVH nodes fetched and spheres tested into
 // O.rays[1] and O.rays[2].
-template <bool STRICT, bool BVH, bool TEX, bool APPROX, bool COUNT = false>
+template <bool STRICT, bool BVH, bool EXT, bool APPROX, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq F, Outputs O) {
+  constexpr bool DIEL = EXT && !APPROX;  // dielectric spheres need exact sphere distances
   __shared__ int stack[bvh_stack_words<BVH>()];
   uint32_t px, py;
   pixel_of_thread(px, py);
@@ -67,12 +68,12 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
         int skip = -1;
         for (int b = 0; b < P.n_bounce; ++b) {
           Hit h;
-          if constexpr (COUNT) h = closest_hit_bvh<true, APPROX>(S, o, d, stack, skip, &cnt_nodes, &cnt_prims);
-          else h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
+          if constexpr (COUNT) h = closest_hit_bvh<true, APPROX, DIEL>(S, o, d, stack, skip, &cnt_nodes, &cnt_prims);
+          else h = closest_hit<BVH, APPROX, false, DIEL>(S, o, d, stack, skip);
           ++nrays;
           if (s == 0 && b == 0) id0 = h.idx;
           if (h.idx >= 0) {
-            skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
+            skip = shade_hit<STRICT, EXT, APPROX>(S, h, skip, rng, o, d, light, colour);
           } else {
             light = fma3v(environment<STRICT>(P, d), colour, light);
             break;
@@ -195,8 +196,9 @@ constexpr int regen_waves(bool strict, bool tex, int form) {
   if (form != kRegenBatched || strict) return RT_MEGA_WAVES;
   return tex ? RT_REGEN_BATCHED_TEX_WAVES : RT_REGEN_BATCHED_WAVES;
 }
-template <bool STRICT, bool BVH, bool TEX, bool APPROX, int FORM>
-__global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+template <bool STRICT, bool BVH, bool EXT, bool APPROX, int FORM>
+__global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+  constexpr bool DIEL = EXT && !APPROX;
   __shared__ int stack[bvh_stack_words<BVH>()];
   // The plain loop is used where one wave's chain of segments sets the launch time: its
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
         bool has_hit = false;
         while (true) {
           if (active && ended == 0 && !has_hit) {
-            const Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
+            const Hit h = closest_hit<BVH, APPROX, false, DIEL>(S, o, d, stack, skip);
             ++nrays;
             if (s == 0 && b == 0) id0 = h.idx;
             if (h.idx >= 0) {
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
             run_end = !run_shade;
           }
           if (run_shade && has_hit) {
-            skip = shade_hit<STRICT, TEX, APPROX>(S, pending, rng, o, d, light, colour);
+            skip = shade_hit<STRICT, EXT, APPROX>(S, pending, skip, rng, o, d, light, colour);
             has_hit = false;
             ++b;
             if (b >= P.n_bounce) ended = 2;
@@ -284,11 +286,11 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
       } else {
         while (true) {
           if (active && ended == 0) {
-            const Hit h = closest_hit<BVH, APPROX>(S, o, d, stack, skip);
+            const Hit h = closest_hit<BVH, APPROX, false, DIEL>(S, o, d, stack, skip);
             ++nrays;
             if (s == 0 && b == 0) id0 = h.idx;
             if (h.idx >= 0) {
-              skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
+              skip = shade_hit<STRICT, EXT, APPROX>(S, h, skip, rng, o, d, light, colour);
               ++b;
               if (b >= P.n_bounce) ended = 2;
             } else {
@@ -308,12 +310,12 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
       uchar4 img = O.rgba8[pix];
       bool active = true;
       while (active) {
-        Hit h = closest_hit<BVH, APPROX, CHAIN>(S, o, d, stack, skip);
+        Hit h = closest_hit<BVH, APPROX, CHAIN, DIEL>(S, o, d, stack, skip);
         ++nrays;
         if (s == 0 && b == 0) id0 = h.idx;
         bool path_done;
         if (h.idx >= 0) {
-          skip = shade_hit<STRICT, TEX, APPROX, CHAIN>(S, h, rng, o, d, light, colour);
+          skip = shade_hit<STRICT, EXT, APPROX, CHAIN>(S, h, skip, rng, o, d, light, colour);
           ++b;
           path_done = b >= P.n_bounce;
         } else {
@@ -397,10 +399,11 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, TEX, FO
 #define RT_SCHED_TALLY(step, n)
 #endif
 
-template <bool STRICT, bool TEX, bool APPROX>
-__global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
+template <bool STRICT, bool EXT, bool APPROX>
+__global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   // [entry][thread], S.stack_entries entries: the launch sizes it by the height of the tree
   // (a 16-level tree leaves room for twice the waves a fixed 32-entry stack would)
+  constexpr bool DIEL = EXT && !APPROX;
   extern __shared__ int stack[];
   const uint32_t tile = ordered_tile(O, tile_rank<kTileBlock>());
   uint32_t px, py;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1)
   f3 light = mk3(0.f, 0.f, 0.f), colour = mk3(1.f, 1.f, 1.f);
   int skip = -1;
   Search<APPROX> Q;
-  search_begin(S, o, d, Q);
+  search_begin<DIEL>(S, o, d, skip, Q);
 
   while (true) {
     const bool want_inner = active && Q.node >= 0;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1)
     } else if (w_leaf >= w_shade) {
       RT_SCHED_TALLY(2, n_leaf);
       if (want_leaf) {
-        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        leaf_candidate<DIEL>(S, ~Q.node, o, d, Q.a, skip, Q.best);
         Q.node = search_pop<kTileBlock>(Q, stack);
       }
     } else {
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1)
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, EXT, APPROX>(S, h, skip, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1)
         }
       }
       if (active) {
-        search_begin(S, o, d, Q);
+        search_begin<DIEL>(S, o, d, skip, Q);
       } else {
         if (!O.probe) O.ids[pix] = id0;
       }
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !TEX) ? RT_SCHED_WAVES : 1)
   tally_wave(O, tile, nrays);
 }
 
-template <bool STRICT, bool BVH, bool TEX, bool APPROX>
+template <bool STRICT, bool BVH, bool EXT, bool APPROX>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
                                 const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
@@ -533,12 +536,12 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     return e[0] == 'p' ? kRegenPlain : e[0] == 'b' ? kRegenBatched : e[0] == 'm' ? kRegenMixed : -1;
   }();
   if (nested)
-    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, TEX, APPROX>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, EXT, APPROX>), grid, block, 0, stream, P, S, F, O);
   else if (BVH && sched)
-    hipLaunchKernelGGL((k_mega_sched<STRICT, TEX, APPROX>), wave_tiles, wave_block,
+    hipLaunchKernelGGL((k_mega_sched<STRICT, EXT, APPROX>), wave_tiles, wave_block,
                        (size_t)S.stack_entries * kTileBlock * sizeof(int), stream, P, S, F, O);
   else if (BVH)
-    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, O);
   else {
     // Brute-force scenes.  Many tiles: throughput is everything, the batched loop.  Fewer: the
     // longest chain sets the time; with a measured order its tiles (and only they) get the
@@ -550,11 +553,11 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     Q.chain_ranks = (O.n_tiles + chain_div - 1u) / chain_div;
     constexpr bool B = !BVH;  // keeps the BVH instantiations of the brute-force forms out of the library
     if (form == kRegenMixed)
-      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenMixed : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenMixed : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else if (form == kRegenBatched)
-      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, B ? kRegenBatched : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else
-      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, TEX, APPROX, kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
   }
   return hipGetLastError();
 }
@@ -562,7 +565,7 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
 hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const FrameSeq &F,
                                       const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
-  if (S.tex)
+  if (S.tex || S.ior)
     hipLaunchKernelGGL((k_mega_nested<false, true, true, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
   else
     hipLaunchKernelGGL((k_mega_nested<false, true, false, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
@@ -571,9 +574,10 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
 
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
                              const FrameSeq &F, const Outputs &O, hipStream_t stream) {
-  // fast policy without a mesh: approximate sphere distances behind exact decisions
-  const bool approx = !strict && S.n_tris == 0u;
-  const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
+  // fast policy without a mesh or dielectric spheres: approximate sphere distances behind
+  // exact decisions
+  const bool approx = !strict && S.n_tris == 0u && !S.ior;
+  const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | ((S.tex || S.ior) ? 1 : 0);
   switch (variant) {
     case 0: return launch_mega_t<false, false, false, false>(nested, P, S, F, O, stream);
     case 1: return launch_mega_t<false, false, true, false>(nested, P, S, F, O, stream);

@@ -144,14 +144,17 @@ __device__ __forceinline__ void triangle_candidate(const float4 *__restrict__ T,
 // index order (the tree): equal distances go to the lower index, which is what the
 // shader's in-order loop with its strict "<" returns.  In an in-order loop the extra clause
 // never fires, so the brute-force search uses it too.
+// FAR (extension: the one dielectric sphere a refracted ray travels inside) takes the other
+// root, dst = (-b + sqrt(disc)) / (2a), with the same acceptance test dst >= 0.
+template <bool FAR = false>
 __device__ __forceinline__ void sphere_candidate_tie(float4 g, int idx, f3 o, f3 d, float a,
                                                      float &best_n, Hit &best) {
   f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
   float bh = dot(oc, d);
   float c = dot(oc, oc) - g.w;
   float disc = __builtin_fmaf(bh, bh, -(a * c));
-  if (disc >= 0.0f && bh <= 0.0f) {
-    float n = -bh - ieee_sqrt(disc);
+  if (disc >= 0.0f && (FAR || bh <= 0.0f)) {
+    float n = FAR ? -bh + ieee_sqrt(disc) : -bh - ieee_sqrt(disc);
     if (n <= best_n && n > -1e-30f) {
       float q = ieee_div(n, a);
       if (q >= 0.0f && (q < best.dst || (q == best.dst && idx < best.idx))) {
@@ -197,6 +200,9 @@ struct Closest<false> {
   template <bool LIKELY = false>
   __device__ __forceinline__ void sphere(float4 g, int idx, f3 o, f3 d, float a) {
     sphere_candidate_tie(g, idx, o, d, a, best_n, best);
+  }
+  __device__ __forceinline__ void sphere_far(float4 g, int idx, f3 o, f3 d, float a) {
+    sphere_candidate_tie<true>(g, idx, o, d, a, best_n, best);
   }
   __device__ __forceinline__ void triangle(const float4 *T, int idx, f3 o, f3 d) {
     triangle_candidate(T, idx, o, d, best_n, best);
@@ -268,8 +274,9 @@ struct Closest<true> {
       }
     }
   }
-  // APPROX kernels are launched only for scenes without a mesh
+  // APPROX kernels are launched only for scenes without a mesh and without dielectric spheres
   __device__ __forceinline__ void triangle(const float4 *, int, f3, f3) {}
+  __device__ __forceinline__ void sphere_far(float4, int, f3, f3, float) {}
   __device__ __forceinline__ float dst() const { return idx != kNoHit ? n * rcp_a : 3.402823466e+38f; }
   __device__ __forceinline__ bool any() const { return idx != kNoHit; }
   __device__ __forceinline__ Hit result() const {
@@ -283,8 +290,10 @@ struct Closest<true> {
   }
 };
 
-// skip: id of the triangle the ray starts on (-1: none); a planar primitive cannot be hit
-// again by a ray that leaves it, and the triangle test has no epsilon.
+// skip: id of the primitive the ray starts on or in (-1: none).  A triangle is left out: a
+// planar primitive cannot be hit again by a ray that leaves it, and the triangle test has no
+// epsilon.  A sphere -- only ever a dielectric one the ray was refracted into, and only in
+// DIEL kernels -- is tested with its far root.
 // Four consecutive geometry records (the array is padded to a multiple of four).
 struct SphereGroup {
   float4 g0, g1, g2, g3;
@@ -301,7 +310,7 @@ __device__ __forceinline__ SphereGroup load_group(const Scene &S, uint32_t i) {
 
 // GROUPED: spheres are fetched four at a time, for code whose running time is one wave's
 // chain of dependent segments rather than the device's throughput.
-template <bool APPROX, bool GROUPED = false>
+template <bool APPROX, bool GROUPED = false, bool DIEL = false>
 __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int skip) {
   const float a = dot(d, d);
   Closest<APPROX> C;
@@ -313,6 +322,16 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int
     // (which hide the bookkeeping behind each other's arithmetic).
     for (uint32_t i = 0; i < n; i += 4u) {
       const SphereGroup G = load_group(S, i);
+      if constexpr (DIEL) {
+        const float4 g[4] = {G.g0, G.g1, G.g2, G.g3};
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+          if (i + k >= n) break;
+          if ((int)(i + k) == skip) C.sphere_far(g[k], (int)(i + k), o, d, a);
+          else C.template sphere<true>(g[k], (int)(i + k), o, d, a);
+        }
+        continue;
+      }
       C.template sphere<true>(G.g0, (int)i, o, d, a);
       if (i + 1u < n) C.template sphere<true>(G.g1, (int)(i + 1u), o, d, a);
       if (i + 2u < n) C.template sphere<true>(G.g2, (int)(i + 2u), o, d, a);
@@ -328,7 +347,8 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int
     if (n) g = load_const(geom);
     for (uint32_t i = 0; i < n; ++i) {
       const float4 g_next = load_const(geom + (i + 1u < n ? i + 1u : i));
-      C.sphere(g, (int)i, o, d, a);
+      if (DIEL && (int)i == skip) C.sphere_far(g, (int)i, o, d, a);
+      else C.sphere(g, (int)i, o, d, a);
       g = g_next;
     }
   }
@@ -502,6 +522,45 @@ __device__ __forceinline__ float scatter(f3 p, f3 n, float smoothness, float4 m_
 
 __device__ __forceinline__ f3 scatter_throughput(f3 colour, f3 albedo, float4 m_specular, float is_spec) {
   return colour * mix3(albedo, mk3(m_specular.x, m_specular.y, m_specular.z), is_spec);  // (:212-213)
+}
+
+// ---- dielectric spheres (extension: the reference's material, ray_tracing.comp:13-20, has no
+// refraction term and its sphere test takes the near root only, :157-161) ----------------
+// A sphere with an index of refraction scatters by Snell's law with Schlick's reflectance
+// instead of :199-207, drawing ONE random number:
+//   ud = normalize(dir); exiting = the ray travels inside this sphere; nl = exiting ? -n : n
+//   eta = exiting ? ior : 1/ior; cos_i = min(-dot(ud, nl), 1); sin2 = max(1 - cos_i^2, 0)
+//   r0 = ((1 - ior) / (1 + ior))^2; reflectance = r0 + (1 - r0) (1 - cos_i)^5; u = randomValue
+//   reflect when eta^2 sin2 > 1 or reflectance > u: dir' = ud - 2 dot(nl, ud) nl
+//   else refract: perp = eta (ud + cos_i nl); dir' = perp - sqrt(|1 - perp.perp|) nl
+// Returns true when the ray was refracted.
+template <bool STRICT>
+__device__ __forceinline__ bool dielectric_scatter(f3 n, float ior, bool exiting, uint32_t &rng, f3 &d) {
+  using M = Math<STRICT>;
+  const f3 ud = M::normalize(d);
+  const f3 nl = exiting ? mk3(-n.x, -n.y, -n.z) : n;
+  const float eta = exiting ? ior : ieee_div(1.0f, ior);
+  float cos_i = -dot(ud, nl);
+  if (cos_i > 1.0f) cos_i = 1.0f;
+  float sin2 = __builtin_fmaf(-cos_i, cos_i, 1.0f);
+  if (sin2 < 0.0f) sin2 = 0.0f;
+  const bool cannot_refract = (eta * eta) * sin2 > 1.0f;
+  float r0 = ieee_div(1.0f - ior, 1.0f + ior);
+  r0 = r0 * r0;
+  const float x = 1.0f - cos_i;
+  const float x2 = x * x;
+  const float reflectance = __builtin_fmaf(1.0f - r0, (x2 * x2) * x, r0);
+  const float u = pcg_float(rng);
+  if (cannot_refract || reflectance > u) {
+    const float dn2 = 2.0f * dot(nl, ud);
+    d = mk3(__builtin_fmaf(-dn2, nl.x, ud.x), __builtin_fmaf(-dn2, nl.y, ud.y),
+            __builtin_fmaf(-dn2, nl.z, ud.z));
+    return false;
+  }
+  const f3 perp = fma3(nl, cos_i, ud) * eta;
+  const float par = -M::sqrt(__builtin_fabsf(1.0f - dot(perp, perp)));
+  d = fma3(nl, par, perp);
+  return true;
 }
 
 // ---- per-frame pixel epilogue (ray_tracing.comp:98-109) ------------------------------

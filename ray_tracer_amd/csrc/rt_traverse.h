@@ -47,15 +47,29 @@ __device__ __forceinline__ BvhNode load_node(const BvhNode *nodes, int node) {
   return nd;
 }
 
-// leaf at sorted position pos: a sphere (geometry in leaf order) or a triangle of the mesh
-template <bool APPROX>
+// leaf at sorted position pos: a sphere (geometry in leaf order) or a triangle of the mesh.
+// skip: the triangle the ray starts on is left out; in DIEL kernels the dielectric sphere it
+// travels inside is tested with its far root (see closest_hit_brute).
+template <bool DIEL = false, bool APPROX>
 __device__ __forceinline__ void leaf_candidate(const Scene &S, int pos, f3 o, f3 d, float a, int skip,
                                                Closest<APPROX> &C) {
   const int prim = (int)scene_u32(S.sorted_prim, (uint32_t)pos);
   if ((uint32_t)prim < S.n_spheres) {
-    C.sphere(scene_f4(S.sorted_geom, (uint32_t)pos), prim, o, d, a);
+    if (DIEL && prim == skip) C.sphere_far(scene_f4(S.sorted_geom, (uint32_t)pos), prim, o, d, a);
+    else C.sphere(scene_f4(S.sorted_geom, (uint32_t)pos), prim, o, d, a);
   } else if (prim != skip) {
     C.triangle(S.tri + 3u * ((uint32_t)prim - S.n_spheres), prim, o, d);
+  }
+}
+
+// the oversized spheres kept out of the tree, tested before it
+template <bool DIEL, bool APPROX>
+__device__ __forceinline__ void large_candidates(const Scene &S, f3 o, f3 d, float a, int skip,
+                                                 Closest<APPROX> &C) {
+  for (uint32_t i = 0; i < S.n_large; ++i) {
+    const int prim = (int)scene_u32(S.large_prim, i);
+    if (DIEL && prim == skip) C.sphere_far(scene_f4(S.large_geom, i), prim, o, d, a);
+    else C.sphere(scene_f4(S.large_geom, i), prim, o, d, a);
   }
 }
 
@@ -63,7 +77,7 @@ __device__ __forceinline__ void leaf_candidate(const Scene &S, int pos, f3 o, f3
 // bytes-per-segment figure; the search itself is identical.
 // `stack` points at kBvhStack * kBlockThreads ints of LDS owned by the calling kernel
 // (entry-major); it is scratch, so a kernel may reuse that memory between searches.
-template <bool COUNT, bool APPROX>
+template <bool COUNT, bool APPROX, bool DIEL = false>
 __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *stack, int skip,
                                                uint32_t *n_nodes = nullptr,
                                                uint32_t *n_prims = nullptr) {
@@ -74,13 +88,11 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
   const f3 inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
                        __builtin_amdgcn_rcpf(d.z));
   const f3 oi = mk3(o.x * inv_d.x, o.y * inv_d.y, o.z * inv_d.z);
-  for (uint32_t i = 0; i < S.n_large; ++i) {
-    C.sphere(scene_f4(S.large_geom, i), (int)scene_u32(S.large_prim, i), o, d, a);
-    if constexpr (COUNT) ++*n_prims;
-  }
+  large_candidates<DIEL>(S, o, d, a, skip, C);
+  if constexpr (COUNT) *n_prims += S.n_large;
   if (S.n_spheres + S.n_tris == 1u) {
     if (S.n_large == 0u) {
-      leaf_candidate(S, 0, o, d, a, skip, C);
+      leaf_candidate<DIEL>(S, 0, o, d, a, skip, C);
       if constexpr (COUNT) ++*n_prims;
     }
   } else {
@@ -97,14 +109,14 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
       int c0 = nd.child0, c1 = nd.child1;
       if (t0 < __builtin_inff() && c0 < 0) {
         if (c0 != kNullLeaf) {
-          leaf_candidate(S, ~c0, o, d, a, skip, C);
+          leaf_candidate<DIEL>(S, ~c0, o, d, a, skip, C);
           if constexpr (COUNT) ++*n_prims;
         }
         t0 = __builtin_inff();
       }
       if (t1 < __builtin_inff() && c1 < 0) {
         if (c1 != kNullLeaf) {
-          leaf_candidate(S, ~c1, o, d, a, skip, C);
+          leaf_candidate<DIEL>(S, ~c1, o, d, a, skip, C);
           if constexpr (COUNT) ++*n_prims;
         }
         t1 = __builtin_inff();
@@ -126,10 +138,10 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
 }
 
 // closest hit through whichever structure the kernel was built for
-template <bool BVH, bool APPROX, bool GROUPED = false>
+template <bool BVH, bool APPROX, bool GROUPED = false, bool DIEL = false>
 __device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stack, int skip) {
-  if constexpr (BVH) return closest_hit_bvh<false, APPROX>(S, o, d, stack, skip);
-  else return closest_hit_brute<APPROX, GROUPED>(S, o, d, skip);
+  if constexpr (BVH) return closest_hit_bvh<false, APPROX, DIEL>(S, o, d, stack, skip);
+  else return closest_hit_brute<APPROX, GROUPED, DIEL>(S, o, d, skip);
 }
 
 // ---- a search whose state outlives the loop iteration ----------------------------------
@@ -165,13 +177,13 @@ struct Search {
   Closest<APPROX> best;
 };
 
-template <bool APPROX>
-__device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, Search<APPROX> &Q) {
+template <bool DIEL = false, bool APPROX>
+__device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, int skip, Search<APPROX> &Q) {
   Q.a = dot(d, d);
   Q.best.reset(Q.a);
   Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
   Q.oi = mk3(o.x * Q.inv_d.x, o.y * Q.inv_d.y, o.z * Q.inv_d.z);
-  for (uint32_t i = 0; i < S.n_large; ++i) Q.best.sphere(scene_f4(S.large_geom, i), (int)scene_u32(S.large_prim, i), o, d, Q.a);
+  large_candidates<DIEL>(S, o, d, Q.a, skip, Q.best);
   Q.sp = 0;
   if (S.n_spheres + S.n_tris == 1u) Q.node = S.n_large ? kSearchOver : ~0;
   else Q.node = 0;
@@ -210,20 +222,37 @@ template <bool BVH>
 constexpr int bvh_stack_words() { return BVH ? kBvhStack * kBlockThreads : 1; }
 
 // One hit bounce: surface at the hit, then the shader's scatter.  Returns the primitive the
-// next segment must skip.  TEX kernels (launched only while a texture is bound) replace the
-// material colour by the texture sample; its coordinates are taken at the hit and the
-// texels are fetched last, when little else is live.  Kernels without TEX carry none of it.
+// next segment must treat specially (see closest_hit_brute's skip).  EXT kernels (launched only
+// while a texture is bound or the scene has dielectric spheres) carry the two extensions: the
+// material colour replaced by a texture sample -- its coordinates are taken at the hit and the
+// texels are fetched last, when little else is live -- and, in kernels that take exact sphere
+// distances (!APPROX), dielectric spheres.  Kernels without EXT carry none of it.
+// from: the skip value the segment that found this hit was traced with.
 // NO_MESH and CENTRE as in hit_surface.
-template <bool STRICT, bool TEX, bool NO_MESH = false, bool CENTRE = false>
-__device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, uint32_t &rng, f3 &o, f3 &d,
-                                         f3 &light, f3 &colour) {
+template <bool STRICT, bool EXT, bool APPROX = false, bool CENTRE = false>
+__device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, int from, uint32_t &rng, f3 &o,
+                                         f3 &d, f3 &light, f3 &colour) {
   f3 p, n;
   float4 mc, me, ms;
-  const int skip = hit_surface<STRICT, NO_MESH, CENTRE>(S, h, o, d, p, n, mc, me, ms);
+  const int skip = hit_surface<STRICT, APPROX, CENTRE>(S, h, o, d, p, n, mc, me, ms);
+  if constexpr (EXT && !APPROX) {
+    if (S.ior && (uint32_t)h.idx < S.n_spheres) {
+      const float ior = scene_f32(S.ior, (uint32_t)h.idx);
+      if (ior > 0.0f) {
+        const bool exiting = from == h.idx;
+        o = p;
+        const bool refracted = dielectric_scatter<STRICT>(n, ior, exiting, rng, d);
+        light = fma3v(mk3(me.x * me.w, me.y * me.w, me.z * me.w), colour, light);
+        colour = colour * mk3(mc.x, mc.y, mc.z);
+        // inside the sphere afterwards: refracted into it, or reflected back while inside
+        return refracted != exiting ? h.idx : -1;
+      }
+    }
+  }
   bool textured = false;
   float tu = 0.0f, tv = 0.0f;
-  if constexpr (TEX) {
-    textured = (uint32_t)h.idx - S.tex->first_prim < S.tex->n_prims;
+  if constexpr (EXT) {
+    textured = S.tex && (uint32_t)h.idx - S.tex->first_prim < S.tex->n_prims;
     if (textured) {
       texture_coords(*S.tex, p, n, tu, tv);
       tu *= S.tex->scale_u;
@@ -232,7 +261,7 @@ __device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, uint32_t 
   }
   const float is_spec = scatter<STRICT>(p, n, mc.w, me, ms.w, rng, o, d, light, colour);
   f3 albedo = mk3(mc.x, mc.y, mc.z);
-  if constexpr (TEX) {
+  if constexpr (EXT) {
     // a specular bounce gives the colour weight 0 and every texel is finite: skip the fetch
     if (textured && is_spec == 0.0f) albedo = texture_sample(*S.tex, tu, tv);
   }

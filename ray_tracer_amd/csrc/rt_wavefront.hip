@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_wf_init(Params P, uint32_t frame, WfVie
   V.alive[i] = 1;
 }
 
-template <bool BVH, bool APPROX>
+template <bool BVH, bool APPROX, bool DIEL>
 __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t slot, uint32_t n_pixels,
                                                    int32_t *ids) {
   __shared__ uint32_t lds[kWfEBrute * 4 + 1];
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
     is_hit[k] = is_miss[k] = false;
     if (pix[k] < n_pixels && V.alive[pix[k]]) {
       const float4 p0 = V.P0[pix[k]], p1 = V.P1[pix[k]];
-      const int skip = S.n_tris ? __float_as_int(V.P2[pix[k]].w) : -1;
-      const Hit h = closest_hit<BVH, APPROX>(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), stack, skip);
+      const int skip = (S.n_tris || DIEL) ? __float_as_int(V.P2[pix[k]].w) : -1;
+      const Hit h = closest_hit<BVH, APPROX, false, DIEL>(S, mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), stack, skip);
       V.H[pix[k]] = make_float2(h.dst, __int_as_float(h.idx));
       if (__float_as_uint(p1.w) == 0u) ids[pix[k]] = h.idx;  // sample 0, bounce 0
       is_hit[k] = h.idx >= 0;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_wf_extend(Scene S, WfView V, uint32_t s
 // on the 10k-sphere scene).  Here the searches of a thread's kWfE entries are strung into one
 // wave-scheduled loop (see rt_traverse.h): inner and leaf steps as in k_mega_sched, and a
 // "next" step that stores the finished search and starts the thread's next live pixel.
-template <bool APPROX>
+template <bool APPROX, bool DIEL>
 __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene S, WfView V, uint32_t slot,
                                                         uint32_t n_pixels, int32_t *ids) {
   __shared__ uint32_t lds[kWfETree * 4 + 1];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene 
       }
     } else if (w_leaf >= w_next) {
       if (want_leaf) {
-        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        leaf_candidate<DIEL>(S, ~Q.node, o, d, Q.a, skip, Q.best);
         Q.node = search_pop(Q, stack);
       }
     } else if (want_next) {
@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene 
       }
       if (k < kWfETree) {
         const float4 p0 = V.P0[pix], p1 = V.P1[pix];
-        skip = S.n_tris ? __float_as_int(V.P2[pix].w) : -1;
+        skip = (S.n_tris || DIEL) ? __float_as_int(V.P2[pix].w) : -1;
         sample0 = __float_as_uint(p1.w) == 0u;  // sample 0, bounce 0
         o = mk3(p0.x, p0.y, p0.z);
         d = mk3(p1.x, p1.y, p1.z);
-        search_begin(S, o, d, Q);
+        search_begin<DIEL>(S, o, d, skip, Q);
       }
     }
   }
@@ -305,7 +305,7 @@ __device__ __forceinline__ bool path_end(const Params &P, const WfView &V, const
   return true;
 }
 
-template <bool STRICT, bool TEX, int E>
+template <bool STRICT, bool EXT, int E>
 __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, uint32_t slot,
                                                   uint32_t frame, Outputs O) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, u
       Hit h{};
       h.dst = hrec.x;
       h.idx = idx;
-      const int skip = shade_hit<STRICT, TEX>(S, h, rng, o, d, light, colour);
+      const int skip = shade_hit<STRICT, EXT>(S, h, __float_as_int(p2.w), rng, o, d, light, colour);
       ++b;
       if (b >= (uint32_t)P.n_bounce) {
         path_end<STRICT>(P, V, O, frame, px, rng, s, light);
@@ -368,9 +368,10 @@ __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels)
 
 // Finishes every pixel of the drain queue in registers: the loop of the regenerating
 // megakernel, resumed from the stored path state, for this one frame.
-template <bool STRICT, bool BVH, bool TEX, bool APPROX>
+template <bool STRICT, bool BVH, bool EXT, bool APPROX>
 __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, uint32_t frame,
                                                   Outputs O) {
+  constexpr bool DIEL = EXT && !APPROX;
   __shared__ int stack[bvh_stack_words<BVH>()];
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
@@ -391,12 +392,12 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
     while (true) {
       // the drain is the chain of the slowest pixels: the brute-force search in its form for a
       // wave running alone, the sphere's centre carried with the hit (as k_mega_regen's plain loop)
-      const Hit h = closest_hit<BVH, APPROX, !BVH>(S, o, d, stack, skip);
+      const Hit h = closest_hit<BVH, APPROX, !BVH, DIEL>(S, o, d, stack, skip);
       ++nrays;
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT, TEX, APPROX, !BVH>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, EXT, APPROX, !BVH>(S, h, skip, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -427,9 +428,10 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
 
 // The drain launch for LBVH scenes: the same resumption, in k_mega_sched's wave-scheduled
 // form (inner / leaf / shade steps chosen by waiting-lane count).
-template <bool STRICT, bool TEX, bool APPROX>
+template <bool STRICT, bool EXT, bool APPROX>
 __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params P, Scene S, WfView V, uint32_t frame,
                                                        Outputs O) {
+  constexpr bool DIEL = EXT && !APPROX;
   extern __shared__ int stack[];  // [entry][thread], S.stack_entries entries (sized by the launch)
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params 
     skip = __float_as_int(p2.w);
   }
   Search<APPROX> Q;
-  search_begin(S, o, d, Q);
+  search_begin<DIEL>(S, o, d, skip, Q);
 
   while (true) {
     const bool want_inner = active && Q.node >= 0;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params 
       }
     } else if (w_leaf >= w_shade) {
       if (want_leaf) {
-        leaf_candidate(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        leaf_candidate<DIEL>(S, ~Q.node, o, d, Q.a, skip, Q.best);
         Q.node = search_pop(Q, stack);
       }
     } else if (want_shade) {
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params 
       if (s == 0 && b == 0) id0 = h.idx;
       bool path_done;
       if (h.idx >= 0) {
-        skip = shade_hit<STRICT, TEX, APPROX>(S, h, rng, o, d, light, colour);
+        skip = shade_hit<STRICT, EXT, APPROX>(S, h, skip, rng, o, d, light, colour);
         ++b;
         path_done = b >= P.n_bounce;
       } else {
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params 
         }
       }
       if (active) {
-        search_begin(S, o, d, Q);
+        search_begin<DIEL>(S, o, d, skip, Q);
       } else {
         float4 acc = O.accum[pix];
         uchar4 img = O.rgba8[pix];
@@ -586,7 +588,7 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
   return 0;
 }
 
-template <bool STRICT, bool BVH, bool TEX, bool APPROX>
+template <bool STRICT, bool BVH, bool EXT, bool APPROX>
 static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const Params &P,
                     const Scene &S, uint32_t frame, const Outputs &O, hipStream_t stream,
                     uint32_t *launches, std::string *err) {
@@ -611,21 +613,21 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
     if (bound <= drain_threshold) {
       hipLaunchKernelGGL(k_wf_compact, dim3(compact_blocks), dim3(256), 0, stream, V, n);
       if constexpr (BVH)
-        hipLaunchKernelGGL((k_wf_drain_tree<STRICT, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), tree_stack_bytes,
+        hipLaunchKernelGGL((k_wf_drain_tree<STRICT, EXT, APPROX>), dim3((bound + 255u) / 256u), dim3(256), tree_stack_bytes,
                            stream, P, S, V, frame, O);
       else
-        hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, TEX, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0,
+        hipLaunchKernelGGL((k_wf_drain<STRICT, BVH, EXT, APPROX>), dim3((bound + 255u) / 256u), dim3(256), 0,
                            stream, P, S, V, frame, O);
       *launches += 2;
       break;
     }
     if constexpr (BVH)
-      hipLaunchKernelGGL((k_wf_extend_tree<APPROX>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
+      hipLaunchKernelGGL((k_wf_extend_tree<APPROX, EXT && !APPROX>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
                          O.ids);
     else
-      hipLaunchKernelGGL((k_wf_extend<BVH, APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+      hipLaunchKernelGGL((k_wf_extend<BVH, APPROX, EXT && !APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                          O.ids);
-    hipLaunchKernelGGL((k_wf_shade<STRICT, TEX, E>), dim3(window_blocks), dim3(256),
+    hipLaunchKernelGGL((k_wf_shade<STRICT, EXT, E>), dim3(window_blocks), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
     *launches += 2;
     if ((it + 1) % kCheckEvery == 0) {
@@ -662,8 +664,8 @@ int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &
   *launches = 0;
   for (uint32_t fi = 0; fi < F.count; ++fi) {
     const uint32_t frame = F.first + fi * F.stride;
-    const bool approx = !strict && S.n_tris == 0u;  // see launch_megakernel
-    const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | (S.tex ? 1 : 0);
+    const bool approx = !strict && S.n_tris == 0u && !S.ior;  // see launch_megakernel
+    const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | ((S.tex || S.ior) ? 1 : 0);
 #define RT_WF_CASE(n, a, b, c, e)                                                             \
   case n:                                                                                     \
     rc = wf_frame<a, b, c, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err);  \

@@ -44,6 +44,17 @@ L.rto_render_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Mes
                                C.POINTER(Texture), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_int]
+class Job(C.Structure):
+    _fields_ = [("ubo272", C.c_void_p), ("spheres64", C.c_void_p), ("n_spheres", C.c_uint32),
+                ("mesh", C.POINTER(Mesh)), ("texture", C.POINTER(Texture)), ("ior", C.c_void_p),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("first_frame", C.c_uint32),
+                ("n_frames", C.c_uint32), ("frame_stride", C.c_uint32), ("math_mode", C.c_int),
+                ("accum_mode", C.c_int), ("pixels", C.c_void_p), ("n_pixels", C.c_uint32),
+                ("accum", C.c_void_p), ("rgba8", C.c_void_p), ("ids", C.c_void_p),
+                ("rays", C.POINTER(C.c_uint64)), ("threads", C.c_int)]
+
+
+L.rto_render_job.argtypes = [C.POINTER(Job)]
 L.rto_texture_sample.argtypes = [C.POINTER(Texture), C.c_float, C.c_float, C.c_void_p]
 L.rto_texture_sample.restype = None
 L.rto_srgb_to_linear.argtypes = [C.c_uint8]
@@ -134,18 +145,29 @@ def pm(name, x, y=None):
 
 def render(ubo, spheres, width, height, first_frame=0, n_frames=1, stride=1,
            math_mode=MATH_PORTABLE, accum_mode=ACCUM_GAMMA, threads=8, accum=None, rgba8=None,
-           mesh=None, texture=None):
+           mesh=None, texture=None, ior=None, pixels=None):
     """Returns dict(accum, rgba8, ids, rays).  accum/rgba8 may be passed in to continue.
     mesh = (vertices (n,3) float32, indices (m,3) uint32, material (12,) float32) or None.
-    texture = dict(rgba8=(h,w,4) uint8, first_prim, n_prims, mapping, scale=(su,sv), srgb) or None."""
+    texture = dict(rgba8=(h,w,4) uint8, first_prim, n_prims, mapping, scale=(su,sv), srgb) or None.
+    ior = (n_spheres,) float32, > 0 marks a dielectric sphere, or None.
+    pixels = 1-D array of pixel indices (y * width + x): only those are shaded and accum,
+    rgba8 and ids come back as compact (len(pixels), ...) arrays in list order."""
     ubo = np.ascontiguousarray(ubo, dtype=np.float32)
     spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 16)
+    if pixels is not None:
+        pixels = np.ascontiguousarray(pixels, dtype=np.uint32).reshape(-1)
+        shape = (pixels.size,)
+    else:
+        shape = (height, width)
     if accum is None:
-        accum = np.zeros((height, width, 4), dtype=np.float32)
+        accum = np.zeros(shape + (4,), dtype=np.float32)
     if rgba8 is None:
-        rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
-    ids = np.full((height, width), -1, dtype=np.int32)
+        rgba8 = np.zeros(shape + (4,), dtype=np.uint8)
+    ids = np.full(shape, -1, dtype=np.int32)
     rays = C.c_uint64(0)
+    if ior is not None:
+        ior = np.ascontiguousarray(ior, dtype=np.float32).reshape(-1)
+        assert ior.size == spheres.shape[0]
     mptr = None
     if mesh is not None:
         v = np.ascontiguousarray(mesh[0], dtype=np.float32).reshape(-1, 3)
@@ -162,11 +184,14 @@ def render(ubo, spheres, width, height, first_frame=0, n_frames=1, stride=1,
                           float(scale[1]), int(texture.get("first_prim", 0)),
                           int(texture.get("n_prims", 1)))
         tptr = C.byref(tstruct)
-    rc = L.rto_render_scene(ubo.ctypes.data_as(C.c_void_p), spheres.ctypes.data_as(C.c_void_p),
-                            spheres.shape[0], mptr, tptr, width, height, first_frame, n_frames,
-                            stride, math_mode, accum_mode, accum.ctypes.data_as(C.c_void_p),
-                            rgba8.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
-                            C.byref(rays), threads)
+    job = Job(ubo.ctypes.data, spheres.ctypes.data if spheres.size else None, spheres.shape[0],
+              C.pointer(mstruct) if mesh is not None else None,
+              C.pointer(tstruct) if texture is not None else None,
+              ior.ctypes.data if ior is not None else None, width, height, first_frame, n_frames,
+              stride, math_mode, accum_mode, pixels.ctypes.data if pixels is not None else None,
+              pixels.size if pixels is not None else 0, accum.ctypes.data, rgba8.ctypes.data,
+              ids.ctypes.data, C.pointer(rays), threads)
+    rc = L.rto_render_job(C.byref(job))
     assert rc == 0
     return dict(accum=accum, rgba8=rgba8, ids=ids, rays=int(rays.value))
 
@@ -177,6 +202,19 @@ def texture_sample(rgba8, u, v, srgb=False):
     out = np.zeros(3, dtype=np.float32)
     L.rto_texture_sample(C.byref(t), u, v, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def dielectric_scatter(direction, normal, ior, exiting, rng_state):
+    """(new direction (3,) float32, refracted bool, rng state after the one draw)"""
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    n = np.ascontiguousarray(normal, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    state = C.c_uint32(rng_state)
+    refracted = C.c_int(0)
+    L.rto_dielectric_scatter(d.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p), C.c_float(ior),
+                             int(exiting), C.byref(state), out.ctypes.data_as(C.c_void_p),
+                             C.byref(refracted))
+    return out, bool(refracted.value), state.value
 
 
 def srgb_to_linear(v):

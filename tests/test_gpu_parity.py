@@ -856,3 +856,120 @@ def test_regen_loop_forms_are_bit_identical():
         assert res.returncode == 0, res.stderr
         out.append([l for l in res.stdout.splitlines() if l.startswith("DIGEST")][0])
     assert out[0] == out[1] == out[2], out
+
+
+# ---------------------------------------------------------------- dielectric spheres (extension)
+def gpu_render_glass(ubo, spheres, ior, w, h, mode, flags, first=0, n=1, stride=1, mesh=None, tex=None):
+    with rt.Renderer(w, h, mode=mode, flags=flags) as r:
+        r.set_params(ubo)
+        r.set_spheres(spheres)
+        r.set_dielectric(ior)
+        if mesh is not None:
+            r.set_mesh(*mesh)
+        if tex is not None:
+            r.set_texture(tex["rgba8"], tex["first_prim"], tex["n_prims"], tex.get("mapping", 0),
+                          tex.get("scale", (1.0, 1.0)), tex.get("srgb", True))
+        r.render(first, n, stride)
+        r.sync()
+        st = r.stats()
+        return dict(accum=r.read_accum(), rgba8=r.read_rgba8(), ids=r.read_primary_ids(),
+                    rays=int(st.rays), stats=st)
+
+
+def _glass_scene():
+    """The reference's three spheres with sphere 0 made of glass, a second glass ball that
+    overlaps sphere 1, a glass ball inside a larger glass ball, and a glass ball the camera sits in."""
+    base = rt.default_scene()
+    rows = [base[0], base[1], base[2]]
+    def ball(x, y, z, r, tint):
+        s = base[0].copy()
+        s[:4] = (x, y, z, r)
+        s[4:7] = tint
+        return s
+    rows.append(ball(2.2, 0.3, -4.2, 0.6, (0.9, 1.0, 0.9)))      # overlaps the red sphere
+    rows.append(ball(-2.5, 0.2, -4.5, 1.0, (1.0, 0.8, 0.8)))     # shell ...
+    rows.append(ball(-2.5, 0.2, -4.5, 0.5, (0.8, 0.8, 1.0)))     # ... around a core
+    rows.append(ball(0.0, 0.0, 0.0, 0.25, (0.95, 0.95, 1.0)))    # the camera is inside this one
+    sph = np.stack(rows).astype(np.float32)
+    sph[0, 8:11] = (0.2, 0.1, 0.0)                               # the glass also glows a little
+    sph[0, 11] = 0.5
+    ior = np.array([1.5, 0, 0, 1.33, 1.5, 2.4, 1.1], np.float32)
+    return sph, ior
+
+
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT])
+@pytest.mark.parametrize("accel", [rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH])
+def test_dielectric_spheres_bit_exact(oracle, mode, accel):
+    w, h = 176, 104
+    ubo = rt.make_ubo(w, h, 3, 12, sun_intensity=2.0)
+    sph, ior = _glass_scene()
+    want = oracle.render(ubo, sph, w, h, 0, 2, 1, ior=ior)
+    plain = oracle.render(ubo, sph, w, h, 0, 2, 1)
+    assert not np.array_equal(want["accum"], plain["accum"]) and want["rays"] != plain["rays"]
+    got = gpu_render_glass(ubo, sph, ior, w, h, mode, rt.FLAG_STRICT_MATH | accel, 0, 2, 1)
+    _assert_exact(got, want)
+
+
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT])
+def test_dielectric_grid_scene_bit_exact(oracle, mode):
+    """The synthetic scene of BASELINE.json configs[2] in small: diffuse / metal / glass classes,
+    through the LBVH, against the brute-force oracle."""
+    w, h = 200, 112
+    ubo = rt.make_ubo(w, h, 2, 10)
+    sph, ior = rt.grid_spheres_scene_glass(1200)
+    assert 0.10 < float((ior > 0).mean()) < 0.20 and ior[0] == 0
+    want = oracle.render(ubo, sph, w, h, ior=ior)
+    got = gpu_render_glass(ubo, sph, ior, w, h, mode, rt.FLAG_STRICT_MATH)
+    assert got["stats"].bvh_nodes == 1199
+    _assert_exact(got, want)
+    # the same spheres as the coated variant; only the glass class differs
+    coated = rt.grid_spheres_scene(1200)
+    assert np.array_equal(coated[:, :4], sph[:, :4])
+    assert np.array_equal(coated[ior == 0], sph[ior == 0])
+
+
+def test_dielectric_with_mesh_and_texture_bit_exact(oracle):
+    """All three extensions in one launch: glass balls over a textured terrain."""
+    w, h = 128, 72
+    ubo = rt.make_ubo(w, h, 2, 10)
+    sph = rt.default_scene()
+    sph[2, :4] = (0, -1000, -5, 1)
+    ior = np.array([1.5, 1.3, 0], np.float32)
+    v, i = rt.terrain_mesh(18, phase=0.3, size=30.0, depth=-14.0)
+    mat = rt.matte(0.7, 0.6, 0.4, smoothness=0.6, specular_probability=0.3)
+    tex = dict(rgba8=rt.brick_texture(96, 96), first_prim=0, n_prims=3 + i.shape[0], scale=(0.3, 0.3), srgb=False)
+    want = oracle.render(ubo, sph, w, h, mesh=(v, i, mat), texture=tex, ior=ior)
+    for mode in (rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT):
+        for accel in (rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH):
+            got = gpu_render_glass(ubo, sph, ior, w, h, mode, rt.FLAG_STRICT_MATH | accel, mesh=(v, i, mat), tex=tex)
+            _assert_exact(got, want)
+
+
+def test_dielectric_fast_mode_and_table_lifetime(oracle):
+    w, h = 192, 108
+    ubo = rt.make_ubo(w, h, 8, 12)
+    sph, ior = _glass_scene()
+    want = oracle.render(ubo, sph, w, h, ior=ior)
+    plain = oracle.render(ubo, sph, w, h)
+    with rt.Renderer(w, h) as r:
+        r.set_params(ubo)
+        r.set_spheres(sph)
+        with pytest.raises(rt.RtError):
+            r.set_dielectric(ior[:3])                      # one value per sphere, or none
+        with pytest.raises(rt.RtError):
+            r.set_dielectric(np.full(len(ior), np.nan, np.float32))
+        r.set_dielectric(ior)
+        r.render(0, 1, 1)
+        # fast math: hardware rsq / sqrt in the scatter; decisions on exact sphere distances
+        assert psnr(r.read_accum()[..., :3], want["accum"][..., :3]) >= 38.0
+        assert abs(r.stats().rays - want["rays"]) <= 5e-3 * want["rays"]
+        r.clear()
+        r.set_dielectric(None)
+        r.render(0, 1, 1)
+        assert psnr(r.read_accum()[..., :3], plain["accum"][..., :3]) >= 40.0
+        r.set_dielectric(ior)
+        r.set_spheres(sph)                                 # a new sphere set drops the table
+        r.clear()
+        r.render(0, 1, 1)
+        assert psnr(r.read_accum()[..., :3], plain["accum"][..., :3]) >= 40.0
+        assert psnr(r.read_accum()[..., :3], want["accum"][..., :3]) < 38.0

@@ -333,3 +333,135 @@ def test_brick_texture_changes_the_ground(oracle):
     assert (diff[ground] > 0).mean() > 0.9          # the ground is recoloured
     sky = plain["ids"] == -1
     assert (diff[sky] == 0).mean() > 0.98          # sky pixels never see it (horizon jitter aside)
+
+
+# ---------------------------------------------------------------- dielectric spheres (extension)
+def _first_draw(oracle, seed):
+    return float(oracle.pcg_stream(seed, 1)[0][2])
+
+
+def _seed_with_draw(oracle, lo, hi):
+    """an RNG state whose next randomValue lies in (lo, hi)"""
+    for seed in range(1, 100000):
+        if lo < _first_draw(oracle, seed) < hi:
+            return seed
+    raise AssertionError("no seed found")
+
+
+def test_dielectric_rule_hand_computed(oracle):
+    """Snell + Schlick, one draw.  Expected values computed here in float64."""
+    ior = 1.5
+    r0 = ((1 - ior) / (1 + ior)) ** 2                                  # 0.04
+    # normal incidence from outside: straight through when u > r0, straight back when u < r0
+    n = np.array([0, 0, 1], np.float32)
+    d = np.array([0, 0, -2.5], np.float32)                              # un-normalised, as the shader's rays are
+    seed = _seed_with_draw(oracle, 0.5, 0.9)
+    out, refracted, state = oracle.dielectric_scatter(d, n, ior, False, seed)
+    assert refracted and np.array_equal(out, np.array([0, 0, -1], np.float32))
+    assert state == oracle.pcg_stream(seed, 1)[0][0]                    # exactly one draw
+    seed = _seed_with_draw(oracle, 0.0, 0.039)
+    out, refracted, _ = oracle.dielectric_scatter(d, n, ior, False, seed)
+    assert not refracted and np.array_equal(out, np.array([0, 0, 1], np.float32))
+    # 45 degrees from outside: Snell's angle and Schlick's reflectance
+    d = np.array([1, 0, -1], np.float32)
+    cos_i = np.cos(np.pi / 4)
+    refl = r0 + (1 - r0) * (1 - cos_i) ** 5                             # 0.04206...
+    seed = _seed_with_draw(oracle, refl + 1e-3, 1.0)
+    out, refracted, _ = oracle.dielectric_scatter(d, n, ior, False, seed)
+    assert refracted
+    sin_t = np.sin(np.pi / 4) / ior
+    want = np.array([sin_t, 0, -np.sqrt(1 - sin_t ** 2)])
+    assert np.max(np.abs(out - want)) < 2e-7 and abs(np.linalg.norm(out.astype(np.float64)) - 1) < 2e-7
+    seed = _seed_with_draw(oracle, refl - 2e-3, refl - 1e-3)           # just under the reflectance
+    out, refracted, _ = oracle.dielectric_scatter(d, n, ior, False, seed)
+    assert not refracted
+    assert np.max(np.abs(out - np.array([1, 0, 1]) / np.sqrt(2))) < 2e-7
+    # from inside, 60 degrees to the (outward) normal: sin_i * ior > 1, total internal reflection
+    # whatever the draw; 30 degrees: refracts away from the normal
+    d = np.array([np.sin(np.pi / 3), 0, np.cos(np.pi / 3)], np.float32)
+    for seed in (_seed_with_draw(oracle, 0.0, 0.01), _seed_with_draw(oracle, 0.99, 1.0)):
+        out, refracted, _ = oracle.dielectric_scatter(d, n, ior, True, seed)
+        assert not refracted
+        assert np.max(np.abs(out - np.array([np.sin(np.pi / 3), 0, -np.cos(np.pi / 3)]))) < 2e-7
+    d = np.array([np.sin(np.pi / 6), 0, np.cos(np.pi / 6)], np.float32)
+    out, refracted, _ = oracle.dielectric_scatter(d, n, ior, True, _seed_with_draw(oracle, 0.5, 1.0))
+    assert refracted
+    sin_t = np.sin(np.pi / 6) * ior
+    assert np.max(np.abs(out - np.array([sin_t, 0, np.sqrt(1 - sin_t ** 2)]))) < 3e-7
+
+
+def _glass_ball_ubo(oracle, w, h, spp, bounces):
+    cam = oracle.camera_create(90.0, 1.0, 0.01, 10000.0)
+    cam.viewport_width, cam.viewport_height = float(w), float(h)
+    ubo = oracle.default_ubo(cam)
+    ubo[40], ubo[41], ubo[66], ubo[67] = spp, bounces, 0, 0
+    return ubo
+
+
+def test_dielectric_ray_through_the_centre(oracle):
+    """Jitter off, centre pixel, a glass ball straight ahead: the path enters at the near root,
+    leaves at the FAR root of the same sphere (which the reference's near-root test can never
+    report) and ends in the sky behind: three segments, throughput = tint squared."""
+    w, h = 64, 64                                        # pixel (32, 32) looks exactly down -Z
+    ubo = _glass_ball_ubo(oracle, w, h, 1, 25)
+    sph = oracle.default_spheres()[:1].copy()
+    sph[0, :4] = (0, 0, -5, 1)
+    sph[0, 4:7] = (0.5, 0.25, 1.0)                       # tint
+    ior = np.array([1.5], np.float32)
+    centre = np.array([(h // 2) * w + w // 2], np.uint32)
+    # find a frame whose two Fresnel draws both refract (probability 0.92)
+    for frame in range(8):
+        r = oracle.render(ubo, sph, w, h, first_frame=frame, ior=ior, pixels=centre, accum_mode=oracle.ACCUM_LINEAR)
+        if r["rays"] == 3:
+            break
+    assert r["rays"] == 3 and r["ids"][0] == 0
+    sky = oracle.render(ubo, np.zeros((0, 16), np.float32), w, h, pixels=centre,
+                        accum_mode=oracle.ACCUM_LINEAR)["accum"][0, :3]
+    want = sky * (np.float32([0.5, 0.25, 1.0]) * np.float32([0.5, 0.25, 1.0]))
+    assert np.array_equal(r["accum"][0, :3], want)
+    # the same ball with the reference's material: one hit, one diffuse or specular bounce
+    plain = oracle.render(ubo, sph, w, h, pixels=centre)
+    assert plain["ids"][0] == 0
+    # ior <= 0 entries leave the reference's model in place, bit for bit
+    off = oracle.render(ubo, sph, w, h, ior=np.zeros(1, np.float32), pixels=centre)
+    assert np.array_equal(off["accum"], plain["accum"]) and off["rays"] == plain["rays"]
+
+
+def test_dielectric_leaves_other_spheres_alone(oracle):
+    """A glass ball among the default spheres: pixels whose paths never touch it keep their
+    bits; an ior table of zeros is the plain scene."""
+    w, h = 96, 64
+    cam = oracle.camera_create(90.0, w / h, 0.01, 10000.0)
+    cam.viewport_width, cam.viewport_height = float(w), float(h)
+    ubo = oracle.default_ubo(cam)
+    ubo[40], ubo[41] = 2, 8
+    sph = oracle.default_spheres()
+    plain = oracle.render(ubo, sph, w, h)
+    glass = oracle.render(ubo, sph, w, h, ior=np.array([1.5, 0, 0], np.float32))
+    assert np.array_equal(glass["ids"], plain["ids"])
+    assert not np.array_equal(glass["accum"], plain["accum"])
+    sky = plain["ids"] == -1
+    same = (glass["accum"] == plain["accum"]).all(-1)
+    assert same[sky].mean() > 0.98
+    zeros = oracle.render(ubo, sph, w, h, ior=np.zeros(3, np.float32))
+    assert np.array_equal(zeros["accum"], plain["accum"]) and zeros["rays"] == plain["rays"]
+
+
+def test_pixel_list_equals_the_whole_image(oracle):
+    """Pixels are independent: a listed pixel gets the bits it has in the full render."""
+    w, h = 80, 50
+    cam = oracle.camera_create(90.0, w / h, 0.01, 10000.0)
+    cam.viewport_width, cam.viewport_height = float(w), float(h)
+    ubo = oracle.default_ubo(cam)
+    ubo[40], ubo[41] = 3, 7
+    sph = oracle.default_spheres()
+    full = oracle.render(ubo, sph, w, h, 1, 2, 3)
+    pix = np.array([0, 17, w * h - 1, 25 * w + 40, 30 * w + 41, 30 * w + 41], np.uint32)   # one listed twice
+    part = oracle.render(ubo, sph, w, h, 1, 2, 3, pixels=pix)
+    assert part["accum"].shape == (6, 4)
+    assert np.array_equal(part["accum"], full["accum"].reshape(-1, 4)[pix])
+    assert np.array_equal(part["rgba8"], full["rgba8"].reshape(-1, 4)[pix])
+    assert np.array_equal(part["ids"], full["ids"].reshape(-1)[pix])
+    every = oracle.render(ubo, sph, w, h, 1, 2, 3, pixels=np.arange(w * h, dtype=np.uint32))
+    assert every["rays"] == full["rays"]
+    assert np.array_equal(every["accum"].reshape(h, w, 4), full["accum"])

@@ -21,7 +21,7 @@ with rt.Renderer(w, h) as r:
         st = r.stats()
         rows.append((st.last_build_ms, (t1 - t0) * 1e3, st.last_render_ms, st.rays - st0.rays, st.bvh_height))
         if f == frames - 1:
-            rt.write_png("gpurun_out/cfg4_terrain.png", r.read_rgba8()[::2, ::2].copy())
+            rt.write_png(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/gpurun_out/cfg4_terrain.png", r.read_rgba8()[::2, ::2].copy())
     for k, (b, wall, ms, rays, ht) in enumerate(rows):
         print(f"frame {k} tris {i.shape[0]} build_ms {b:.3f} set_mesh_wall_ms {wall:.1f} trace_ms {ms:.3f} "
               f"rays {rays} Mrays/s {rays / ms / 1e3:.0f} height {ht}", flush=True)

@@ -35,4 +35,4 @@ for mode, name in ((rt.MODE_MEGAKERNEL, "megakernel"),):
         print(f"{name} textured=True all 16 frames: {s1.last_render_ms:.1f} ms, rays {s1.rays - s0.rays}, "
               f"{(s1.rays - s0.rays) / s1.last_render_ms / 1e3:.0f} Mrays/s", flush=True)
         img = r.read_rgba8()
-        rt.write_png("gpurun_out/cfg5_textured.png", img[::8, ::8].copy())
+        rt.write_png(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/gpurun_out/cfg5_textured.png", img[::8, ::8].copy())
