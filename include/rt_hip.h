@@ -52,7 +52,9 @@ enum {
   RT_FLAG_FORCE_BVH = 1u << 3,
   /* measurement aid: megakernel + LBVH + fast math only; also counts the LBVH nodes
    * fetched and the spheres tested (rt_stats.bvh_nodes_visited / bvh_spheres_tested).
-   * Slower; results are unchanged. */
+   * Slower.  Hit ids are unchanged; the counting kernel takes exact sphere distances where the
+   * default kernel takes them from the hardware sqrt/rcp units, so colours agree with a normal
+   * launch to fast-math tolerance, not bit for bit. */
   RT_FLAG_COUNT_TRAVERSAL = 1u << 4
 };
 
@@ -151,7 +153,9 @@ int rt_set_dielectric(rt_ctx *ctx, const float *ior, uint32_t count);
  * main.cpp:819-868, for n_frames dispatches with ubo.frame.x = first_frame,
  * first_frame + frame_stride, ...  (main.cpp:1028 increments it by one per
  * dispatch).  Every pixel is shaded (ceil-div grid with a bounds guard).
- * Asynchronous: returns after enqueueing on the context's stream. */
+ * Megakernel modes are asynchronous: the call returns after enqueueing on the context's
+ * stream.  RT_MODE_WAVEFRONT reads the live-path count back every few iterations to decide
+ * how many more stages to launch, so the call blocks for most of the frame. */
 int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride);
 
 /* Replaces vkWaitForFences on the compute fence, main.cpp:872-874. */

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,23 @@ int trip_count(float limit) {
   float c = std::ceil(limit);
   if (c > 16777216.0f) c = 16777216.0f;
   return (int)c;
+}
+
+// No exception crosses the C ABI: the bodies of the entry points that touch containers or
+// strings run inside this.
+template <class F>
+int guarded(const char *who, F body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(RT_ERR_NOMEM, "%s: out of host memory", who);
+  } catch (const std::length_error &) {
+    return fail(RT_ERR_NOMEM, "%s: size exceeds what a host container can hold", who);
+  } catch (const std::exception &e) {
+    return fail(RT_ERR_INVALID, "%s: %s", who, e.what());
+  } catch (...) {
+    return fail(RT_ERR_INVALID, "%s: unknown exception", who);
+  }
 }
 
 }  // namespace
@@ -175,10 +193,14 @@ int rebuild_accel(rt_ctx *c) {
   int rc = c->bvh.build(c->d_geom, c->h_spheres.data(), c->n_spheres, c->d_tri, c->mesh_lo,
                         c->mesh_hi, c->n_tris, cam, c->stream, &err);
   if (rc != RT_OK) return fail(rc, "LBVH build: %s", err.c_str());
-  if (c->bvh.height > (uint32_t)rt::kBvhStackEntries)
-    return fail(RT_ERR_INVALID, "LBVH height %u exceeds the traversal stack (%d)", c->bvh.height,
-                rt::kBvhStackEntries);
   std::memcpy(c->bvh_cam, cam, sizeof cam);
+  if (c->bvh.height > (uint32_t)rt::kBvhStackEntries) {
+    // taller than any launch can give a stack for: trace by brute force (correct, slow) and
+    // say so; the upload itself succeeds
+    fail(RT_OK, "LBVH height %u exceeds the traversal stack (%d): scene is traced by brute force",
+         c->bvh.height, rt::kBvhStackEntries);
+    return RT_OK;
+  }
   c->use_bvh = true;
   return RT_OK;
 }
@@ -187,10 +209,13 @@ int rebuild_accel(rt_ctx *c) {
 
 extern "C" {
 
+int rt_destroy(rt_ctx *c);
+int rt_clear(rt_ctx *c);
+
 const char *rt_last_error(void) { return g_last_error.c_str(); }
 const char *rt_version(void) { return "rt_hip 0.1 (gfx950)"; }
 
-int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
+static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
   if (!cfg || !out_ctx) return fail(RT_ERR_INVALID, "rt_create: null argument");
   if (cfg->struct_size != sizeof(rt_config))
     return fail(RT_ERR_INVALID, "rt_create: struct_size %u, expected %zu", cfg->struct_size,
@@ -303,7 +328,7 @@ int rt_clear(rt_ctx *c) {
   return RT_OK;
 }
 
-int rt_set_params(rt_ctx *c, const void *ubo272) {
+static int rt_set_params_impl(rt_ctx *c, const void *ubo272) {
   if (!c || !ubo272) return fail(RT_ERR_INVALID, "rt_set_params: null argument");
   rt_ubo u;
   std::memcpy(&u, ubo272, sizeof u);
@@ -354,7 +379,7 @@ int rt_set_params(rt_ctx *c, const void *ubo272) {
   return RT_OK;
 }
 
-int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
+static int rt_set_spheres_impl(rt_ctx *c, const void *spheres64, uint32_t count) {
   if (!c) return fail(RT_ERR_INVALID, "rt_set_spheres: null context");
   if (count && !spheres64) return fail(RT_ERR_INVALID, "rt_set_spheres: null data");
   if (count > (1u << 26)) return fail(RT_ERR_INVALID, "rt_set_spheres: %u spheres", count);
@@ -404,7 +429,7 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
   return RT_OK;
 }
 
-int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
+static int rt_set_mesh_impl(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
                 uint32_t n_triangles, const rt_material *material) {
   if (!c) return fail(RT_ERR_INVALID, "rt_set_mesh: null context");
   if (n_triangles && (!vertices || !indices || !material))
@@ -470,7 +495,9 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
   c->n_tris = n_triangles;
   c->order_interval = 1;
   c->launches_since_order = 0;
-  if (!c->d_material) {  // no spheres uploaded yet: an empty sphere set
+  if (!c->d_material) {  // no spheres uploaded yet (or an upload failed half way): an empty sphere set
+    if (c->d_geom) RT_HIP(hipFree(c->d_geom));
+    c->d_geom = nullptr;
     RT_HIP(hipMalloc(&c->d_geom, 4 * sizeof(float4)));
     RT_HIP(hipMemset(c->d_geom, 0, 4 * sizeof(float4)));
     RT_HIP(hipMalloc(&c->d_material, 3 * sizeof(float4)));
@@ -484,7 +511,7 @@ int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uin
   return RT_OK;
 }
 
-int rt_set_dielectric(rt_ctx *c, const float *ior, uint32_t count) {
+static int rt_set_dielectric_impl(rt_ctx *c, const float *ior, uint32_t count) {
   if (!c) return fail(RT_ERR_INVALID, "rt_set_dielectric: null context");
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));  // launches in flight may still read the old table
@@ -509,7 +536,7 @@ int rt_set_dielectric(rt_ctx *c, const float *ior, uint32_t count) {
   return RT_OK;
 }
 
-int rt_set_texture(rt_ctx *c, const rt_texture_desc *desc, const void *rgba8) {
+static int rt_set_texture_impl(rt_ctx *c, const rt_texture_desc *desc, const void *rgba8) {
   if (!c) return fail(RT_ERR_INVALID, "rt_set_texture: null context");
   if (desc) {
     if (desc->struct_size != sizeof(rt_texture_desc))
@@ -561,7 +588,7 @@ int rt_set_texture(rt_ctx *c, const rt_texture_desc *desc, const void *rgba8) {
   return RT_OK;
 }
 
-int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride) {
+static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride) {
   if (!c) return fail(RT_ERR_INVALID, "rt_render: null context");
   if (!c->have_params) return fail(RT_ERR_STATE, "rt_render: rt_set_params has not been called");
   if (!c->have_scene) return fail(RT_ERR_STATE, "rt_render: rt_set_spheres has not been called");
@@ -692,7 +719,7 @@ int rt_accum_device_ptr(rt_ctx *c, void **out_dptr, size_t *out_bytes) {
   return RT_OK;
 }
 
-int rt_get_stats(rt_ctx *c, rt_stats *out) {
+static int rt_get_stats_impl(rt_ctx *c, rt_stats *out) {
   if (!c || !out) return fail(RT_ERR_INVALID, "rt_get_stats: null argument");
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
@@ -732,6 +759,39 @@ int rt_debug_eval(int device, int op, const float *a, const float *b, float *out
   if (db) hipFree(db);
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_debug_eval: %s", hipGetErrorString(e));
   return RT_OK;
+}
+
+int rt_create(const rt_config *cfg, rt_ctx **out_ctx) {
+  return guarded("rt_create", [&] { return rt_create_impl(cfg, out_ctx); });
+}
+
+int rt_set_params(rt_ctx *c, const void *ubo272) {
+  return guarded("rt_set_params", [&] { return rt_set_params_impl(c, ubo272); });
+}
+
+int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
+  return guarded("rt_set_spheres", [&] { return rt_set_spheres_impl(c, spheres64, count); });
+}
+
+int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
+                uint32_t n_triangles, const rt_material *material) {
+  return guarded("rt_set_mesh", [&] { return rt_set_mesh_impl(c, vertices, n_vertices, indices, n_triangles, material); });
+}
+
+int rt_set_dielectric(rt_ctx *c, const float *ior, uint32_t count) {
+  return guarded("rt_set_dielectric", [&] { return rt_set_dielectric_impl(c, ior, count); });
+}
+
+int rt_set_texture(rt_ctx *c, const rt_texture_desc *desc, const void *rgba8) {
+  return guarded("rt_set_texture", [&] { return rt_set_texture_impl(c, desc, rgba8); });
+}
+
+int rt_render(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride) {
+  return guarded("rt_render", [&] { return rt_render_impl(c, first_frame, n_frames, frame_stride); });
+}
+
+int rt_get_stats(rt_ctx *c, rt_stats *out) {
+  return guarded("rt_get_stats", [&] { return rt_get_stats_impl(c, out); });
 }
 
 }  // extern "C"

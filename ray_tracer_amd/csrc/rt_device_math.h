@@ -6,9 +6,10 @@
 //           same bits.
 //   Fast    the same calls map to the CDNA transcendental unit (v_sin/v_cos/v_log/
 //           v_exp/v_sqrt/v_rsq, ~1 ulp, 8 issue cycles per wave instruction).
-// Geometry (ray generation without jitter, ray-sphere roots, hit points, normals)
-// uses IEEE sqrt and divide under BOTH policies, so the primitive a ray hits does
-// not depend on the policy.
+// Every accept/reject decision of the closest-hit search equals the IEEE arithmetic's under
+// BOTH policies (rt_shading.h, Closest), so the primitive a ray hits does not depend on the
+// policy; ray generation without jitter is IEEE too.  The fast policy takes hit distances and
+// surface normals from the hardware sqrt / rcp / rsq units.
 //
 // This translation unit family is compiled with -ffp-contract=off: the compiler
 // never fuses on its own; every fused multiply-add is written as fmaf().

@@ -42,7 +42,11 @@ struct BvhNode {
   int32_t count1;
 };
 
-constexpr int kBvhStackEntries = 32;  // traversal stack entries per lane (>= tree height)
+// Most traversal stack entries a launch can provide per lane: 64 KB of LDS for a 256-thread
+// block.  A Karras tree over 30-bit codes is at most 30 + log2(primitives sharing one cell)
+// levels high, so taller trees need > 2^34 primitives in one cell; such a scene is traced by
+// brute force.
+constexpr int kBvhStackEntries = 64;
 constexpr int kMaxLargeSpheres = 16;  // oversized spheres tested outside the tree
 constexpr int32_t kNullLeaf = (int32_t)0x80000000;  // leaf slot of a sphere kept out of the tree
 

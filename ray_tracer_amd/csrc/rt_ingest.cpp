@@ -299,7 +299,7 @@ const char *rt_ingest_error(void) { return g_ingest_error.c_str(); }
 
 void rt_free(void *p) { std::free(p); }
 
-int rt_load_obj(const char *path, float **out_vertices, uint32_t *out_n_vertices, uint32_t **out_indices,
+static int rt_load_obj_impl(const char *path, float **out_vertices, uint32_t *out_n_vertices, uint32_t **out_indices,
                 uint32_t *out_n_triangles) {
   if (!path || !out_vertices || !out_n_vertices || !out_indices || !out_n_triangles)
     return ingest_fail("rt_load_obj: null argument");
@@ -374,7 +374,7 @@ int rt_load_obj(const char *path, float **out_vertices, uint32_t *out_n_vertices
   return 0;
 }
 
-int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgba8, uint32_t *out_width,
+static int rt_decode_jpeg_impl(const void *bytes, size_t size, int flip_y, uint8_t **out_rgba8, uint32_t *out_width,
                    uint32_t *out_height) {
   if (!bytes || !out_rgba8 || !out_width || !out_height) return ingest_fail("rt_decode_jpeg: null argument");
   Decoder D;
@@ -510,11 +510,37 @@ int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgb
   return 0;
 }
 
-int rt_load_jpeg(const char *path, int flip_y, uint8_t **out_rgba8, uint32_t *out_width, uint32_t *out_height) {
+static int rt_load_jpeg_impl(const char *path, int flip_y, uint8_t **out_rgba8, uint32_t *out_width, uint32_t *out_height) {
   if (!path) return ingest_fail("rt_load_jpeg: null path");
   std::vector<uint8_t> bytes;
   if (!read_file(path, bytes)) return ingest_fail("rt_load_jpeg: cannot read file");
-  return rt_decode_jpeg(bytes.data(), bytes.size(), flip_y, out_rgba8, out_width, out_height);
+  return rt_decode_jpeg_impl(bytes.data(), bytes.size(), flip_y, out_rgba8, out_width, out_height);
+}
+
+int rt_load_obj(const char *path, float **out_vertices, uint32_t *out_n_vertices, uint32_t **out_indices,
+                uint32_t *out_n_triangles) {
+  try {
+    return rt_load_obj_impl(path, out_vertices, out_n_vertices, out_indices, out_n_triangles);
+  } catch (...) {
+    return ingest_fail("rt_load_obj: out of memory");
+  }
+}
+
+int rt_decode_jpeg(const void *bytes, size_t size, int flip_y, uint8_t **out_rgba8, uint32_t *out_width,
+                   uint32_t *out_height) {
+  try {
+    return rt_decode_jpeg_impl(bytes, size, flip_y, out_rgba8, out_width, out_height);
+  } catch (...) {
+    return ingest_fail("rt_decode_jpeg: out of memory");
+  }
+}
+
+int rt_load_jpeg(const char *path, int flip_y, uint8_t **out_rgba8, uint32_t *out_width, uint32_t *out_height) {
+  try {
+    return rt_load_jpeg_impl(path, flip_y, out_rgba8, out_width, out_height);
+  } catch (...) {
+    return ingest_fail("rt_load_jpeg: out of memory");
+  }
 }
 
 }  // extern "C"

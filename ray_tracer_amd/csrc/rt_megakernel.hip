@@ -46,7 +46,7 @@ namespace rt {
 template <bool STRICT, bool BVH, bool EXT, bool APPROX, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq F, Outputs O) {
   constexpr bool DIEL = EXT && !APPROX;  // dielectric spheres need exact sphere distances
-  __shared__ int stack[bvh_stack_words<BVH>()];
+  extern __shared__ int stack[];  // BVH: [entry][thread], S.stack_entries entries (sized by the launch)
   uint32_t px, py;
   pixel_of_thread(px, py);
   uint32_t nrays = 0, cnt_nodes = 0, cnt_prims = 0;
@@ -199,7 +199,7 @@ constexpr int regen_waves(bool strict, bool tex, int form) {
 template <bool STRICT, bool BVH, bool EXT, bool APPROX, int FORM>
 __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   constexpr bool DIEL = EXT && !APPROX;
-  __shared__ int stack[bvh_stack_words<BVH>()];
+  extern __shared__ int stack[];  // BVH: [entry][thread], S.stack_entries entries (sized by the launch)
   // The plain loop is used where one wave's chain of segments sets the launch time: its
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
   // sphere's centre to the shading code instead of having it fetched again.
@@ -535,13 +535,15 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     if (!e) return -1;
     return e[0] == 'p' ? kRegenPlain : e[0] == 'b' ? kRegenBatched : e[0] == 'm' ? kRegenMixed : -1;
   }();
+  // LDS of the kernels that run one whole tree search per segment: a stack per thread, as deep as the tree
+  const size_t block_stack = BVH ? (size_t)S.stack_entries * 256u * sizeof(int) : 0;
   if (nested)
-    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, EXT, APPROX>), grid, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, EXT, APPROX>), grid, block, block_stack, stream, P, S, F, O);
   else if (BVH && sched)
     hipLaunchKernelGGL((k_mega_sched<STRICT, EXT, APPROX>), wave_tiles, wave_block,
                        (size_t)S.stack_entries * kTileBlock * sizeof(int), stream, P, S, F, O);
   else if (BVH)
-    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain>), tiles, block, 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain>), tiles, block, block_stack, stream, P, S, F, O);
   else {
     // Brute-force scenes.  Many tiles: throughput is everything, the batched loop.  Fewer: the
     // longest chain sets the time; with a measured order its tiles (and only they) get the
@@ -565,10 +567,11 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
 hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const FrameSeq &F,
                                       const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
+  const size_t block_stack = (size_t)S.stack_entries * 256u * sizeof(int);
   if (S.tex || S.ior)
-    hipLaunchKernelGGL((k_mega_nested<false, true, true, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<false, true, true, false, true>), grid, dim3(256), block_stack, stream, P, S, F, O);
   else
-    hipLaunchKernelGGL((k_mega_nested<false, true, false, false, true>), grid, dim3(256), 0, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<false, true, false, false, true>), grid, dim3(256), block_stack, stream, P, S, F, O);
   return hipGetLastError();
 }
 

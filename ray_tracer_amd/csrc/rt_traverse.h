@@ -14,7 +14,6 @@
 
 namespace rt {
 
-constexpr int kBvhStack = kBvhStackEntries;  // entries per lane; the host checks the tree height
 constexpr int kBlockThreads = 256;
 
 // Entry distance of the ray into a box, +inf when it misses or the box is beyond limit.
@@ -75,8 +74,9 @@ __device__ __forceinline__ void large_candidates(const Scene &S, f3 o, f3 d, flo
 
 // COUNT adds two per-lane tallies (nodes fetched, primitives tested) for the roofline's
 // bytes-per-segment figure; the search itself is identical.
-// `stack` points at kBvhStack * kBlockThreads ints of LDS owned by the calling kernel
-// (entry-major); it is scratch, so a kernel may reuse that memory between searches.
+// `stack` points at S.stack_entries * kBlockThreads ints of LDS owned by the calling kernel
+// (entry-major, sized by the launch from the height of the tree); it is scratch, so a kernel
+// may reuse that memory between searches.
 template <bool COUNT, bool APPROX, bool DIEL = false>
 __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *stack, int skip,
                                                uint32_t *n_nodes = nullptr,
@@ -217,9 +217,12 @@ __device__ __forceinline__ void search_inner_step(const Scene &S, Search<APPROX>
   }
 }
 
-// LDS words a kernel must provide for the traversal stack (1 keeps the array legal)
+// static LDS of kernels that are only ever built without a tree (1 word keeps the array legal)
 template <bool BVH>
-constexpr int bvh_stack_words() { return BVH ? kBvhStack * kBlockThreads : 1; }
+constexpr int bvh_stack_words() {
+  static_assert(!BVH, "tree kernels size their stack at launch (dynamic LDS)");
+  return 1;
+}
 
 // One hit bounce: surface at the hit, then the shader's scatter.  Returns the primitive the
 // next segment must treat specially (see closest_hit_brute's skip).  EXT kernels (launched only

@@ -555,16 +555,17 @@ void WavefrontState::release() {
     }                                                                         \
   } while (0)
 
+// On failure the state stays consistent: whatever is missing (read-back ring, events, slab) is
+// created by the next call, and n_pixels is 0 until the slab exists.
 static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) {
-  if (impl && impl->n_pixels == n) return 0;
-  if (impl) {
-    if (impl->slab) hipFree(impl->slab);
-    impl->slab = nullptr;
-  } else {
-    impl = new WavefrontState::Impl();
-    WF_HIP(hipHostMalloc((void **)&impl->h_counts, 16 * sizeof(uint32_t)));
-    for (auto &e : impl->ev) WF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
+  if (impl && impl->slab && impl->n_pixels == n) return 0;
+  if (!impl) impl = new WavefrontState::Impl();
+  if (impl->slab) hipFree(impl->slab);
+  impl->slab = nullptr;
+  impl->n_pixels = 0;
+  if (!impl->h_counts) WF_HIP(hipHostMalloc((void **)&impl->h_counts, 16 * sizeof(uint32_t)));
+  for (auto &e : impl->ev)
+    if (!e) WF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t slices = (n + 256 * kWfETree - 1) / (256 * kWfETree);  // the finer slicing
   const size_t f4 = n * sizeof(float4), q = (n + 256 * kWfEBrute) * sizeof(uint32_t);
   const size_t sl = ((slices * sizeof(uint2) + 255) / 256) * 256;

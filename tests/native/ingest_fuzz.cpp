@@ -74,6 +74,35 @@ int main(int argc, char **argv) {
     }
   }
 
+  // Short final segments: the declared length fits the file, the fields the segment must hold
+  // do not (a quantisation table, a frame header, a scan header, a Huffman table, a restart
+  // interval).  Each buffer is allocated at its exact size so that a read past its end is one
+  // past the allocation.  All must be rejected.
+  {
+    const std::vector<std::vector<uint8_t>> cut = {
+        {0xFF, 0xD8, 0xFF, 0xDB, 0x00, 0x03, 0x00},
+        {0xFF, 0xD8, 0xFF, 0xC0, 0x00, 0x02},
+        {0xFF, 0xD8, 0xFF, 0xDA, 0x00, 0x02},
+        {0xFF, 0xD8, 0xFF, 0xC4, 0x00, 0x03, 0x00},
+        {0xFF, 0xD8, 0xFF, 0xDD, 0x00, 0x02},
+        {0xFF, 0xD8, 0xFF, 0xC0, 0x00, 0x08, 0x08, 0x00, 0x10, 0x00, 0x10, 0x03},
+        {0xFF, 0xD8, 0xFF, 0xDB, 0x00, 0x04, 0x10, 0x01},
+    };
+    for (const std::vector<uint8_t> &c : cut) {
+      uint8_t *exact = (uint8_t *)std::malloc(c.size());
+      std::memcpy(exact, c.data(), c.size());
+      uint8_t *px = nullptr;
+      uint32_t w = 0, h = 0;
+      const int rc = rt_decode_jpeg(exact, c.size(), 0, &px, &w, &h);
+      std::free(exact);
+      if (rc == 0) {
+        std::fprintf(stderr, "a %zu-byte file with a short final segment was accepted\n", c.size());
+        return 1;
+      }
+      ++rejected;
+    }
+  }
+
   const char *words[] = {"v", "f", "vn", "vt", "#", "o", "1", "2", "3", "-1", "-2", "0", "1/1", "2//3",
                          "3/2/1", "1e9", "-0.5", "nan", "x", "/", "99999999999999999999", "\r", "\t", " ",
                          "\n", "\n", "\n", "4", "1.5", "f 1 2 3", "v 0 0 0"};
