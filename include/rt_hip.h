@@ -191,6 +191,43 @@ int rt_accum_device_ptr(rt_ctx *ctx, void **out_dptr, size_t *out_bytes);
 /* Waits for the stream, then reports counters. */
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 
+/* No counterpart in the reference: ONE entry point that allocates nothing, for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation.  It is rt_render for a brute-force sphere scene without a context: one
+ * call repacks the scene, measures tile costs with a two-sample probe and renders n_frames
+ * frames with the megakernel, all enqueued on `stream`, and issues no hipMalloc / hipFree, no
+ * events and no host-device copies.  What rt_create and rt_set_spheres otherwise allocate (the
+ * repacked scene, the tile cost and order tables) lives in a static device array of about
+ * 1.2 MB that every GPU the library runs on holds until the process ends.
+ *   ubo272       HOST: the shader's 272-byte uniform block (frame.x ignored), read during the call
+ *   d_spheres64  DEVICE: n_spheres records of 64 bytes, read by the launches
+ *   d_accum      DEVICE: width*height float4, read-modify-written like rt_render's accumulation image
+ *   d_rgba8      DEVICE: width*height uchar4, the 8-bit progressive image, read-modify-written
+ *   d_ids        DEVICE: width*height int32, primary-hit ids, written
+ *   d_rays       DEVICE or NULL: one uint64, += path segments traced
+ *   flags        RT_FLAG_STRICT_MATH and RT_FLAG_ACCUM_LINEAR only
+ * Limits (RT_ERR_INVALID beyond them): n_spheres <= RT_STATIC_MAX_SPHERES; at most
+ * RT_STATIC_MAX_TILES tiles of 16x16 pixels (a 7680x4320 image has 129,600).  Results equal
+ * rt_render's on a context created with RT_FLAG_FORCE_BRUTE, bit for bit.  Every call on a
+ * GPU uses that GPU's one array: calls whose launches overlap on one GPU (different streams or
+ * host threads) race; calls on one stream are ordered and safe. */
+#define RT_STATIC_MAX_SPHERES 1024u
+#define RT_STATIC_MAX_TILES 139264u
+typedef struct rt_static_job {
+  uint32_t struct_size;   /* sizeof(rt_static_job) */
+  int32_t device;
+  void *stream;           /* hipStream_t, or NULL for the null stream */
+  uint32_t width, height;
+  uint32_t flags;
+  uint32_t n_spheres;
+  const void *ubo272;
+  const void *d_spheres64;
+  uint32_t first_frame, n_frames, frame_stride;
+  uint32_t reserved;      /* 0 */
+  void *d_accum, *d_rgba8, *d_ids, *d_rays;
+} rt_static_job;
+int rt_render_static(const rt_static_job *job);
+
 /* Test hook, no counterpart in the reference: evaluates one device math routine
  * elementwise on host arrays so tests can compare it bit for bit with the CPU.
  * op: 0 sqrt(a) 1 a/b 2 sin(a) 3 cos(a) 4 log(a) 5 log2(a) 6 exp2(a) 7 pow(a,b)

@@ -28,6 +28,9 @@ from ._capi import (  # noqa: F401
     default_scene,
     default_ubo,
     exported_symbols,
+    render_static,
+    STATIC_MAX_SPHERES,
+    STATIC_MAX_TILES,
     lib,
     ubo_set_camera,
     write_png,
@@ -40,5 +43,5 @@ __all__ = [
     "FLAG_ACCUM_LINEAR", "FLAG_COUNT_TRAVERSAL", "FLAG_FORCE_BRUTE", "FLAG_FORCE_BVH", "FLAG_STRICT_MATH",
     "Camera", "Renderer", "RtError", "Stats", "debug_eval", "default_scene", "default_ubo",
     "TEX_MAP_OCTAHEDRAL", "TEX_MAP_PLANAR_XZ", "brick_texture",
-    "decode_jpeg", "load_obj", "exported_symbols", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "grid_spheres_scene_glass", "make_ubo", "matte", "terrain_mesh",
+    "decode_jpeg", "load_obj", "exported_symbols", "render_static", "STATIC_MAX_SPHERES", "STATIC_MAX_TILES", "lib", "ubo_set_camera", "write_png", "write_ppm", "grid_spheres_scene", "grid_spheres_scene_glass", "make_ubo", "matte", "terrain_mesh",
 ]

@@ -350,6 +350,36 @@ class Renderer:
         return st
 
 
+STATIC_MAX_SPHERES = 1024
+STATIC_MAX_TILES = 139264
+
+
+class _StaticJob(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("flags", C.c_uint32),
+                ("n_spheres", C.c_uint32), ("ubo272", C.c_void_p), ("d_spheres64", C.c_void_p),
+                ("first_frame", C.c_uint32), ("n_frames", C.c_uint32), ("frame_stride", C.c_uint32),
+                ("reserved", C.c_uint32), ("d_accum", C.c_void_p), ("d_rgba8", C.c_void_p),
+                ("d_ids", C.c_void_p), ("d_rays", C.c_void_p)]
+
+
+lib.rt_render_static.argtypes = [C.POINTER(_StaticJob)]
+
+
+def render_static(width: int, height: int, ubo: np.ndarray, d_spheres64: int, n_spheres: int,
+                  d_accum: int, d_rgba8: int, d_ids: int, d_rays: int = 0, first_frame: int = 0,
+                  n_frames: int = 1, stride: int = 1, flags: int = 0, device: int = 0,
+                  stream: int = 0) -> None:
+    """rt_render_static: the entry point that allocates nothing.  The d_* arguments are device
+    addresses (for example torch tensors' data_ptr()); ubo is the 272-byte block on the host."""
+    ubo = np.ascontiguousarray(ubo, dtype=np.float32)
+    assert ubo.nbytes == 272
+    job = _StaticJob(C.sizeof(_StaticJob), device, stream or None, width, height, flags, n_spheres,
+                     ubo.ctypes.data, d_spheres64 or None, first_frame, n_frames, stride, 0,
+                     d_accum or None, d_rgba8 or None, d_ids or None, d_rays or None)
+    _check(lib.rt_render_static(C.byref(job)))
+
+
 def exported_symbols() -> List[Tuple[str, bool]]:
     """Every function declared in include/*.h paired with whether the library exports it."""
     names: List[str] = []

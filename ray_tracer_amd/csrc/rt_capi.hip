@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -328,12 +329,10 @@ int rt_clear(rt_ctx *c) {
   return RT_OK;
 }
 
-static int rt_set_params_impl(rt_ctx *c, const void *ubo272) {
-  if (!c || !ubo272) return fail(RT_ERR_INVALID, "rt_set_params: null argument");
+// The kernels' parameter block from the shader's 272-byte uniform block, for a width x height image
+static void fill_params(const void *ubo272, uint32_t width, uint32_t height, rt::Params &P) {
   rt_ubo u;
   std::memcpy(&u, ubo272, sizeof u);
-  const rt::Params before = c->P;
-  rt::Params &P = c->P;
   rt::mat4_inverse(u.view, P.inv_view);
   rt::mat4_inverse(u.projection, P.inv_proj);
   P.viewport_w = u.viewport_size[0];
@@ -354,14 +353,21 @@ static int rt_set_params_impl(rt_ctx *c, const void *ubo272) {
   P.sun_intensity = u.sun_intensity;
   P.defocus = u.defocus_strength;
   P.diverge = u.diverge_strength;
-  P.width = c->width;
-  P.height = c->height;
-  P.fwidth = (float)c->width;
-  P.fheight = (float)c->height;
+  P.width = width;
+  P.height = height;
+  P.fwidth = (float)width;
+  P.fheight = (float)height;
   P.defocus_over_w = P.defocus / P.fwidth;
   P.diverge_over_w = P.diverge / P.fwidth;
   P.rcp_w = 1.0f / P.fwidth;
   P.rcp_h = 1.0f / P.fheight;
+}
+
+static int rt_set_params_impl(rt_ctx *c, const void *ubo272) {
+  if (!c || !ubo272) return fail(RT_ERR_INVALID, "rt_set_params: null argument");
+  const rt::Params before = c->P;
+  rt::Params &P = c->P;
+  fill_params(ubo272, c->width, c->height, P);
   if (!c->have_params || std::memcmp(&before, &P, sizeof P) != 0) {
     c->order_interval = 1;  // a new view: measure tile costs afresh
     c->launches_since_order = 0;
@@ -758,6 +764,119 @@ int rt_debug_eval(int device, int op, const float *a, const float *b, float *out
   hipFree(dout);
   if (db) hipFree(db);
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_debug_eval: %s", hipGetErrorString(e));
+  return RT_OK;
+}
+
+// ---- rt_render_static: the entry point that allocates nothing ---------------------------------
+// Scratch of rt_render_static: the repacked scene and the tile cost / order tables that
+// rt_create and rt_set_spheres otherwise allocate.  One copy per GPU, held until the process
+// ends.  Host code never uses the array's name as an address (it is a host-side stand-in):
+// the device address comes from hipGetSymbolAddress, once per device.
+namespace {
+constexpr uint32_t kStaticGeomEntries = RT_STATIC_MAX_SPHERES + 8u;  // padded to whole groups of four, + one group
+constexpr size_t kStaticGeomBytes = (size_t)kStaticGeomEntries * sizeof(float4);
+constexpr size_t kStaticMaterialBytes = ((size_t)RT_STATIC_MAX_SPHERES + 1u) * 3u * sizeof(float4);
+constexpr size_t kStaticTileBytes = (size_t)RT_STATIC_MAX_TILES * sizeof(uint32_t);
+constexpr size_t kStaticOffMaterial = kStaticGeomBytes;
+constexpr size_t kStaticOffCost = (kStaticOffMaterial + kStaticMaterialBytes + 255u) / 256u * 256u;
+constexpr size_t kStaticOffOrder = kStaticOffCost + kStaticTileBytes;
+constexpr size_t kStaticOffRays = kStaticOffOrder + kStaticTileBytes;
+constexpr size_t kStaticBytes = kStaticOffRays + 256u;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char *g_scratch_ptr[kMaxDevices];  // per device: where ITS copy of `scratch` lives
+std::mutex g_scratch_mutex;
+
+// device address of this device's scratch array (the device must be current)
+int static_scratch(int device, unsigned char **out) {
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void *p = nullptr;
+    RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(RT_ERR_DEVICE, "rt_render_static: no address for the scratch array on device %d", device);
+    g_scratch_ptr[device] = (unsigned char *)p;
+  }
+  *out = g_scratch_ptr[device];
+  return RT_OK;
+}
+}  // namespace
+
+int rt_render_static(const rt_static_job *job) {
+  if (!job) return fail(RT_ERR_INVALID, "rt_render_static: null job");
+  if (job->struct_size != sizeof(rt_static_job))
+    return fail(RT_ERR_INVALID, "rt_render_static: struct_size %u, expected %zu", job->struct_size,
+                sizeof(rt_static_job));
+  if (!job->ubo272 || !job->d_accum || !job->d_rgba8 || !job->d_ids || (job->n_spheres && !job->d_spheres64))
+    return fail(RT_ERR_INVALID, "rt_render_static: null pointer");
+  if (job->width == 0 || job->height == 0 || job->width > 65536u || job->height > 65536u)
+    return fail(RT_ERR_INVALID, "rt_render_static: bad image size %ux%u", job->width, job->height);
+  const uint32_t tiles_x = (job->width + 15u) / 16u;
+  const uint64_t n_tiles64 = (uint64_t)tiles_x * ((job->height + 15u) / 16u);
+  if (n_tiles64 > RT_STATIC_MAX_TILES)
+    return fail(RT_ERR_INVALID, "rt_render_static: %llu tiles of 16x16 pixels, at most %u fit the static tables",
+                (unsigned long long)n_tiles64, (unsigned)RT_STATIC_MAX_TILES);
+  if (job->n_spheres > RT_STATIC_MAX_SPHERES)
+    return fail(RT_ERR_INVALID, "rt_render_static: %u spheres, at most %u fit the static scene", job->n_spheres,
+                (unsigned)RT_STATIC_MAX_SPHERES);
+  if (job->flags & ~(uint32_t)(RT_FLAG_STRICT_MATH | RT_FLAG_ACCUM_LINEAR))
+    return fail(RT_ERR_INVALID, "rt_render_static: flags 0x%x (strict math and linear accumulation only)", job->flags);
+  if (job->frame_stride == 0) return fail(RT_ERR_INVALID, "rt_render_static: frame_stride must be >= 1");
+  if (job->device < 0 || job->device >= kMaxDevices)
+    return fail(RT_ERR_INVALID, "rt_render_static: device %d", job->device);
+  if (job->n_frames == 0) return RT_OK;
+  RT_HIP(hipSetDevice(job->device));
+  unsigned char *base = nullptr;
+  int rc = static_scratch(job->device, &base);
+  if (rc != RT_OK) return rc;
+  hipStream_t stream = (hipStream_t)job->stream;
+  const uint32_t n_tiles = (uint32_t)n_tiles64;
+  float4 *geom = (float4 *)base;
+  float4 *material = (float4 *)(base + kStaticOffMaterial);
+  uint32_t *tile_cost = (uint32_t *)(base + kStaticOffCost);
+  uint32_t *tile_order = (uint32_t *)(base + kStaticOffOrder);
+  unsigned long long *rays = job->d_rays ? (unsigned long long *)job->d_rays
+                                         : (unsigned long long *)(base + kStaticOffRays);
+
+  rt::Params P{};
+  fill_params(job->ubo272, job->width, job->height, P);
+  // the array keeps the last call's contents: the scene is rewritten (padding included) and the
+  // costs restart from zero
+  const uint32_t n_geom = (job->n_spheres + 3u) / 4u * 4u + 4u;
+  RT_HIP(rt::launch_repack_spheres(job->d_spheres64, job->n_spheres, n_geom, geom, material, stream));
+  RT_HIP(hipMemsetAsync(tile_cost, 0, (size_t)n_tiles * sizeof(uint32_t), stream));
+
+  rt::Scene S{};
+  S.geom = geom;
+  S.material = material;
+  S.n_spheres = job->n_spheres;
+  rt::FrameSeq F{job->first_frame, job->n_frames, job->frame_stride};
+  rt::Outputs O{};
+  O.accum = (float4 *)job->d_accum;
+  O.rgba8 = (uchar4 *)job->d_rgba8;
+  O.ids = (int32_t *)job->d_ids;
+  O.rays = rays;
+  O.linear_accum = (job->flags & RT_FLAG_ACCUM_LINEAR) ? 1u : 0u;
+  O.tiles_x = tiles_x;
+  O.n_tiles = n_tiles;
+  O.tile_cost = tile_cost;
+  const bool strict = (job->flags & RT_FLAG_STRICT_MATH) != 0;
+  const bool degenerate = P.n_spp < 1 || P.n_bounce < 1;
+  if (!degenerate && (uint64_t)P.n_spp * job->n_frames >= 32u) {
+    // as rt_render's first launch on a context: a two-sample cost probe, then heaviest tiles first
+    rt::Params probe_params = P;
+    probe_params.n_spp = std::min(probe_params.n_spp, 2);
+    rt::Outputs probe_out = O;
+    probe_out.probe = 1u;
+    RT_HIP(rt::launch_megakernel(false, strict, false, probe_params, S, rt::FrameSeq{job->first_frame, 1u, 1u},
+                                 probe_out, stream));
+    RT_HIP(rt::launch_tile_order(tile_cost, tile_order, n_tiles, stream));
+    O.tile_order = tile_order;
+  }
+  RT_HIP(rt::launch_megakernel(degenerate, strict, false, P, S, F, O, stream));
   return RT_OK;
 }
 

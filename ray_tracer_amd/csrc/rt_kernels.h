@@ -22,6 +22,10 @@ hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
 // position of the first out-of-range index (or ~0) and the ordered-bit bounds of the vertices
 hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, const uint32_t *indices,
                                    uint32_t n_tris, float4 *tri, uint32_t *report, hipStream_t stream);
+// 64-byte sphere records resident on the device -> geometry (n_geom > n entries, zero-padded)
+// and material arrays
+hipError_t launch_repack_spheres(const void *spheres64, uint32_t n, uint32_t n_geom, float4 *geom,
+                                 float4 *material, hipStream_t stream);
 // tile costs of the last launch -> heaviest-first launch order; clears the costs
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,

@@ -31,6 +31,38 @@ hipError_t launch_resolve(const float4 *accum, uchar4 *rgba8, uint32_t n_pixels,
   return hipGetLastError();
 }
 
+// 64-byte sphere records (device) -> the renderer's split layout: geom[i] = centre.xyz, r*r;
+// material[3i..3i+2] = colour, emission, specular.  geom is written for n_geom >= n entries,
+// zeros past n (the brute-force search reads whole groups of four), and the material slot of
+// the (absent) mesh at index n is zeroed.
+__global__ __launch_bounds__(256) void k_repack_spheres(const float4 *__restrict__ spheres64, uint32_t n,
+                                                        uint32_t n_geom, float4 *__restrict__ geom,
+                                                        float4 *__restrict__ material) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_geom) return;
+  if (i < n) {
+    const float4 a = spheres64[4u * i];
+    geom[i] = make_float4(a.x, a.y, a.z, a.w * a.w);
+    material[3u * i + 0u] = spheres64[4u * i + 1u];
+    material[3u * i + 1u] = spheres64[4u * i + 2u];
+    material[3u * i + 2u] = spheres64[4u * i + 3u];
+  } else {
+    geom[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i == n) {
+      material[3u * n + 0u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      material[3u * n + 1u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      material[3u * n + 2u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+hipError_t launch_repack_spheres(const void *spheres64, uint32_t n, uint32_t n_geom, float4 *geom,
+                                 float4 *material, hipStream_t stream) {
+  hipLaunchKernelGGL(k_repack_spheres, dim3((n_geom + 255u) / 256u), dim3(256), 0, stream,
+                     (const float4 *)spheres64, n, n_geom, geom, material);
+  return hipGetLastError();
+}
+
 // order-preserving map float -> uint for atomicMin / atomicMax, and back
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
   const uint32_t u = __float_as_uint(f);
