@@ -109,6 +109,13 @@ int rt_set_spheres(rt_ctx *ctx, const void *spheres64, uint32_t count);
 int rt_set_mesh(rt_ctx *ctx, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
                 uint32_t n_triangles, const rt_material *material);
 
+/* The same with vertices and indices already resident in device memory (same layouts), for a
+ * mesh that another kernel animates every frame: nothing crosses the host-device link.  The
+ * arrays are read during the call, which returns after the acceleration structure is rebuilt;
+ * material is host memory. */
+int rt_set_mesh_device(rt_ctx *ctx, const float *d_vertices, uint32_t n_vertices,
+                       const uint32_t *d_indices, uint32_t n_triangles, const rt_material *material);
+
 /* Stands in for the sampled image the reference declares but never binds: loadTexture
  * (main.cpp:1384-1409, no call site) would create an RGBA8 image with a LINEAR / REPEAT,
  * single-level sampler (vulkan_texture.cpp:77-95), and the compute shader has no sampler

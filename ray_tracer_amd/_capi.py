@@ -118,6 +118,7 @@ lib.rt_destroy.argtypes = [C.c_void_p]
 lib.rt_set_params.argtypes = [C.c_void_p, C.c_void_p]
 lib.rt_set_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 lib.rt_set_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+lib.rt_set_mesh_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
 lib.rt_set_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 lib.rt_set_dielectric.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 lib.rt_brick_texture.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
@@ -289,6 +290,14 @@ class Renderer:
         m = np.ascontiguousarray(material, dtype=np.float32).reshape(12)
         _check(lib.rt_set_mesh(self._ctx, v.ctypes.data_as(C.c_void_p), v.shape[0],
                                i.ctypes.data_as(C.c_void_p), i.shape[0], m.ctypes.data_as(C.c_void_p)))
+
+    def set_mesh_device(self, d_vertices: int, n_vertices: int, d_indices: int, n_triangles: int,
+                        material: np.ndarray) -> None:
+        """The same from device memory: d_vertices / d_indices are device addresses of
+        n_vertices * 3 float32 and n_triangles * 3 uint32."""
+        m = np.ascontiguousarray(material, dtype=np.float32).reshape(12)
+        _check(lib.rt_set_mesh_device(self._ctx, d_vertices, n_vertices, d_indices, n_triangles,
+                                      m.ctypes.data_as(C.c_void_p)))
 
     def set_texture(self, rgba8: Optional[np.ndarray], first_prim: int = 0, n_prims: int = 1,
                     mapping: int = TEX_MAP_PLANAR_XZ, scale=(1.0, 1.0), srgb: bool = True) -> None:

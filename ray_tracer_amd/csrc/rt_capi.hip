@@ -85,6 +85,9 @@ struct rt_ctx {
 
   float4 *d_tri = nullptr;       // v0, v1, v2 per mesh triangle
   uint32_t n_tris = 0;
+  uint32_t n_tris_alloc = 0;     // triangles d_tri was allocated for
+  float4 *d_tri_spare = nullptr; // the previous mesh's array, reused by an upload of the same size
+  uint32_t tri_spare_n = 0;
   float mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0};  // bounds of the mesh vertices
   float mesh_material[12] = {0};
 
@@ -299,6 +302,7 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_geom) hipFree(c->d_geom);
   if (c->d_material) hipFree(c->d_material);
   if (c->d_tri) hipFree(c->d_tri);
+  if (c->d_tri_spare) hipFree(c->d_tri_spare);
   if (c->d_ior) hipFree(c->d_ior);
   if (c->d_texels) hipFree(c->d_texels);
   if (c->d_tex_lut) hipFree(c->d_tex_lut);
@@ -435,8 +439,9 @@ static int rt_set_spheres_impl(rt_ctx *c, const void *spheres64, uint32_t count)
   return RT_OK;
 }
 
-static int rt_set_mesh_impl(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
-                uint32_t n_triangles, const rt_material *material) {
+// on_device: vertices and indices are device addresses (rt_set_mesh_device), else host memory
+static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
+                    uint32_t n_triangles, const rt_material *material, bool on_device) {
   if (!c) return fail(RT_ERR_INVALID, "rt_set_mesh: null context");
   if (n_triangles && (!vertices || !indices || !material))
     return fail(RT_ERR_INVALID, "rt_set_mesh: null data");
@@ -453,21 +458,42 @@ static int rt_set_mesh_impl(rt_ctx *c, const float *vertices, uint32_t n_vertice
     float *d_v = nullptr;
     uint32_t *d_i = nullptr, *d_report = nullptr;
     uint32_t report[7];
-    hipError_t e = hipMalloc(&d_v, (size_t)n_vertices * 3 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&d_i, (size_t)n_triangles * 3 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_report, sizeof report);
-    if (e == hipSuccess) e = hipMalloc(&new_tri, (size_t)n_triangles * 3 * sizeof(float4));
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(d_v, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(d_i, indices, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice,
-                         c->stream);
+    hipError_t e = hipMalloc(&d_report, sizeof report);
+    // the triangle array of the previous mesh is reused when the new one has as many triangles
+    // and a spare exists (a mesh re-uploaded every frame then allocates nothing here)
+    if (e == hipSuccess) {
+      if (c->d_tri_spare && c->tri_spare_n == n_triangles) {
+        new_tri = c->d_tri_spare;
+        c->d_tri_spare = nullptr;
+      } else {
+        e = hipMalloc(&new_tri, (size_t)n_triangles * 3 * sizeof(float4));
+      }
+    }
+    if (on_device) {
+      d_v = const_cast<float *>(vertices);
+      d_i = const_cast<uint32_t *>(indices);
+    } else {
+      if (e == hipSuccess) e = hipMalloc(&d_v, (size_t)n_vertices * 3 * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc(&d_i, (size_t)n_triangles * 3 * sizeof(uint32_t));
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(d_v, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(d_i, indices, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                           c->stream);
+    }
     if (e == hipSuccess)
       e = rt::launch_expand_triangles(d_v, n_vertices, d_i, n_triangles, new_tri, d_report, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(report, d_report, sizeof report, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_v);
-    hipFree(d_i);
+    uint32_t bad_index = 0;
+    if (e == hipSuccess && report[0] != 0xffffffffu) {
+      if (on_device) e = hipMemcpy(&bad_index, d_i + report[0], sizeof bad_index, hipMemcpyDeviceToHost);
+      else bad_index = indices[report[0]];
+    }
+    if (!on_device) {
+      hipFree(d_v);
+      hipFree(d_i);
+    }
     hipFree(d_report);
     if (e != hipSuccess) {
       hipFree(new_tri);
@@ -475,8 +501,8 @@ static int rt_set_mesh_impl(rt_ctx *c, const float *vertices, uint32_t n_vertice
     }
     if (report[0] != 0xffffffffu) {
       hipFree(new_tri);
-      return fail(RT_ERR_INVALID, "rt_set_mesh: index %u at position %u, %u vertices", indices[report[0]],
-                  report[0], n_vertices);
+      return fail(RT_ERR_INVALID, "rt_set_mesh: index %u at position %u, %u vertices", bad_index, report[0],
+                  n_vertices);
     }
     for (int k = 0; k < 3; ++k) {  // ordered bits back to floats
       auto back = [](uint32_t u) {
@@ -493,8 +519,12 @@ static int rt_set_mesh_impl(rt_ctx *c, const float *vertices, uint32_t n_vertice
   c->have_scene = false;  // restored once everything below has succeeded (see rt_set_spheres)
   c->use_bvh = false;
   c->n_tris = 0;
-  if (c->d_tri) RT_HIP(hipFree(c->d_tri));
+  // the outgoing triangle array becomes the spare for the next upload of the same size
+  if (c->d_tri_spare) RT_HIP(hipFree(c->d_tri_spare));
+  c->d_tri_spare = c->d_tri;
+  c->tri_spare_n = c->n_tris_alloc;
   c->d_tri = new_tri;
+  c->n_tris_alloc = n_triangles;
   if (material) std::memcpy(c->mesh_material, material, sizeof c->mesh_material);
   std::memcpy(c->mesh_lo, lo, sizeof lo);
   std::memcpy(c->mesh_hi, hi, sizeof hi);
@@ -894,7 +924,13 @@ int rt_set_spheres(rt_ctx *c, const void *spheres64, uint32_t count) {
 
 int rt_set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
                 uint32_t n_triangles, const rt_material *material) {
-  return guarded("rt_set_mesh", [&] { return rt_set_mesh_impl(c, vertices, n_vertices, indices, n_triangles, material); });
+  return guarded("rt_set_mesh", [&] { return set_mesh(c, vertices, n_vertices, indices, n_triangles, material, false); });
+}
+
+int rt_set_mesh_device(rt_ctx *c, const float *d_vertices, uint32_t n_vertices, const uint32_t *d_indices,
+                       uint32_t n_triangles, const rt_material *material) {
+  return guarded("rt_set_mesh_device",
+                 [&] { return set_mesh(c, d_vertices, n_vertices, d_indices, n_triangles, material, true); });
 }
 
 int rt_set_dielectric(rt_ctx *c, const float *ior, uint32_t count) {
