@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s (every path segment) of the path-tracing hot path.
+"""Benchmark of the path-tracing hot path: Mrays/s, counting every path segment.
 
-Workload (BASELINE.json configs[1]): the reference's default 3-sphere scene at
-1920x1080, 64 samples per pixel per frame, at most 25 bounces, camera viewport set to
-the image size.  One step = one frame batch of the hot path per GPU: zero the float
-accumulation image, render one 64-spp frame into it, (N > 1: sum the N accumulation
-images onto rank 0 with one RCCL reduce over xGMI,) resolve to the 8-bit image.  With
-N GPUs rank r renders frame index step*N + r -- the sample-wise split whose frames
-carry the shader's own per-frame RNG streams -- so per-GPU work is fixed (weak
-scaling) and every step yields an N*64-spp image on rank 0.  For N > 1 each rank keeps
-two accumulation images: the reduce of step i runs on RCCL's stream while step i+1 is
-traced into the other image, and rank 0 resolves step i when its sum has landed; all
-K renders, K reduces and K resolves lie inside the timed region.
+Default workload = BASELINE.json configs[1], the configuration the metric is quoted on: the
+reference's 3-sphere scene at 1920x1080, 64 samples per pixel per frame, at most 25 bounces,
+camera viewport set to the image size.  One step = one frame batch per GPU: zero the float
+accumulation image, render into it, (N > 1: sum the N accumulation images onto rank 0 with one
+RCCL reduce over xGMI,) resolve to the 8-bit image.  With N GPUs rank r renders frame
+step*N + r -- the sample-wise split whose frames carry the shader's own per-frame RNG streams
+-- so per-GPU work is fixed (weak scaling) and every step yields an N*64-spp image on rank 0.
+For N > 1 each rank keeps two accumulation images: the reduce of step i runs on RCCL's stream
+while step i+1 is traced into the other image; all K renders, K reduces and K resolves lie
+inside the timed region.
+
+--config N selects another BASELINE.json workload (each prints its own roofline block):
+  0  default scene 1280x720, 1 spp                       weak: one frame per GPU per step
+  1  default scene 1920x1080, 64 spp (the default)       weak: one frame per GPU per step
+  2  10,000 spheres (diffuse / metal / glass), LBVH, 3840x2160, 256 spp = 8 frames x 32 spp
+     per step                                            strong: the 8 frames are split over the GPUs
+  3  1,002,528-triangle terrain, LBVH rebuilt from device-resident vertices every step,
+     1920x1080, 8 spp, 8 bounces                         one GPU (N > 1: independent replicas)
+  4  default scene with a brick texture on the ground, 7680x4320, 16 progressive frames x 50
+     spp per step                                        strong: the 16 frames are split over the GPUs
 
 Prints ONE JSON line on rank 0.  Launch for N > 1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -30,8 +39,28 @@ if ROOT not in sys.path:
 # peaks from the MI355X micro-architecture guide
 PEAK_FP32_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PEAK_L2_GBS = 34500.0
 
-WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 64, 25
+WORKLOADS = {
+    0: dict(name="configs[0]", w=1280, h=720, spp=1, bounces=25, frames=1, scaling="weak", scene="default",
+            text="reference default scene (3 spheres, main.cpp:517-538), 1280x720, 1 spp/frame, maxBounce 25, "
+                 "1 frame per GPU per step (BASELINE.json configs[0])"),
+    1: dict(name="configs[1]", w=1920, h=1080, spp=64, bounces=25, frames=1, scaling="weak", scene="default",
+            text="reference default scene (3 spheres, main.cpp:517-538), 1920x1080, 64 spp/frame, maxBounce 25, "
+                 "1 frame per GPU per step (BASELINE.json configs[1])"),
+    2: dict(name="configs[2]", w=3840, h=2160, spp=32, bounces=25, frames=8, scaling="strong", scene="grid",
+            text="10,000 spheres (rt_grid_scene_glass, seed 1337: 60 % diffuse, 25 % metal, 15 % glass ior 1.5), "
+                 "GPU LBVH, 3840x2160, 256 spp = 8 frames x 32 spp per step, maxBounce 25, frames split over "
+                 "the GPUs (BASELINE.json configs[2])"),
+    3: dict(name="configs[3]", w=1920, h=1080, spp=8, bounces=8, frames=1, scaling="weak", scene="terrain",
+            text="1,002,528-triangle terrain (709x709 height field) + 2 spheres, vertices resident on the device, "
+                 "LBVH rebuilt every step for a new phase of the surface, 1920x1080, 8 spp, maxBounce 8 "
+                 "(BASELINE.json configs[3])"),
+    4: dict(name="configs[4]", w=7680, h=4320, spp=50, bounces=25, frames=16, scaling="strong", scene="textured",
+            text="reference default scene with a 1024x1024 brick texture on the ground sphere, 7680x4320, 16 "
+                 "progressive frames x 50 spp per step, maxBounce 25, frames split over the GPUs "
+                 "(BASELINE.json configs[4])"),
+}
 
 
 def algorithmic_flops(rays: float, samples: float, n_spheres: int) -> float:
@@ -47,47 +76,106 @@ def algorithmic_flops(rays: float, samples: float, n_spheres: int) -> float:
     return rays * (5 + 20 * n_spheres) + hits * 123.0 + samples * 70.0
 
 
-def cpu_baseline(ubo, spheres, threads: int):
+def cpu_baseline(wl, scene, threads: int):
     """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload:
-    one full frame of the benchmark workload (all 64 spp), timed once."""
+    every pixel of one frame while that is seconds of work (the 3-sphere scenes), otherwise a
+    strided sample of the pixels through the oracle's pixel-list entry, sized for 10-30 s."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import _oracle as oracle
-    ubo = ubo.copy()
-    spp = SPP
-    ubo[40] = float(spp)
+    w, h = wl["w"], wl["h"]
+    kw = dict(threads=threads)
+    if scene.get("ior") is not None:
+        kw["ior"] = scene["ior"]
+    if scene.get("mesh") is not None:
+        kw["mesh"] = scene["mesh"]
+    if scene.get("tex") is not None:
+        kw["texture"] = scene["tex"]
+    ubo = scene["ubo"].copy()
+    n_prims = scene["spheres"].shape[0] + (scene["mesh"][1].shape[0] if scene.get("mesh") is not None else 0)
+    # segments the CPU manages in ~15 s: ~180 M segments x 3 spheres on 16 threads per second
+    budget_tests = 2.5e9 * threads / 16.0 * 15.0
+    per_pixel = wl["spp"] * 2.0 * max(n_prims, 3)
+    n_pix = int(min(w * h, max(256, budget_tests / per_pixel)))
+    if wl["name"] == "configs[4]":
+        n_pix = min(n_pix, w * h // 16)
+    if n_pix >= w * h:
+        sample = f"all {w}x{h} pixels"
+        pixels = None
+    else:
+        stride = max(1, (w * h) // n_pix)
+        pixels = np.arange(stride // 2, w * h, stride, dtype=np.uint32)
+        sample = f"{pixels.size} of {w * h} pixels (every {stride}th)"
+        kw["pixels"] = pixels
     t0 = time.perf_counter()
-    res = oracle.render(ubo, spheres, WIDTH, HEIGHT, 0, 1, 1, threads=threads)
+    res = oracle.render(ubo, scene["spheres"], w, h, 0, 1, 1, **kw)
     dt = time.perf_counter() - t0
     return {
         "value": res["rays"] / dt / 1e6,
         "unit": "Mrays/s",
         "cores": threads,
+        "nproc": os.cpu_count(),
         "kind": "port",
-        "sample": f"same scene {WIDTH}x{HEIGHT}, {spp} spp (of {SPP}), maxBounce {BOUNCES}, "
-                  f"frame 0: {res['rays']} rays in {dt:.2f} s",
+        "sample": f"same scene and settings, frame 0, {wl['spp']} spp, {sample}: {res['rays']} rays in {dt:.2f} s "
+                  f"(brute force over {n_prims} primitives, as the shader's loop)",
     }
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the benchmarked kernel from the committed rocprofv3 --pmc
-    passes (profiles/: FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE).
-    bench.py cannot collect hardware counters itself; None if no profile is committed."""
+def pmc_entry(config: int):
+    """Counter figures of the benchmarked kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_latest.json; FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE).
+    bench.py cannot collect hardware counters itself; {} if no profile is committed."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return float(d["hbm_bytes_per_launch"]), d.get("source", path), d
+        if "configs" in d:
+            return d["configs"].get(str(config), {})
+        return d if config == 1 else {}
     except Exception:
-        return None, None, {}
+        return {}
+
+
+def build_scene(rt, np, wl):
+    w, h = wl["w"], wl["h"]
+    scene = dict(ubo=rt.make_ubo(w, h, wl["spp"], wl["bounces"]), ior=None, mesh=None, tex=None)
+    if wl["scene"] == "grid":
+        scene["spheres"], scene["ior"] = rt.grid_spheres_scene_glass(10000)
+    elif wl["scene"] == "terrain":
+        scene["spheres"] = rt.default_scene()[:2]
+        v, i = rt.terrain_mesh(709, phase=0.0)
+        scene["mesh"] = (v, i, rt.matte(0.55, 0.5, 0.4, smoothness=0.7, specular_probability=0.15))
+    elif wl["scene"] == "textured":
+        scene["spheres"] = rt.default_scene()
+        scene["tex"] = dict(rgba8=rt.brick_texture(1024, 1024), first_prim=2, n_prims=1, scale=(0.25, 0.25))
+    else:
+        scene["spheres"] = rt.default_scene()
+    return scene
+
+
+def apply_scene(r, rt, scene):
+    r.set_params(scene["ubo"])
+    r.set_spheres(scene["spheres"])
+    if scene["ior"] is not None:
+        r.set_dielectric(scene["ior"])
+    if scene["mesh"] is not None:
+        r.set_mesh(*scene["mesh"])
+    if scene["tex"] is not None:
+        t = scene["tex"]
+        r.set_texture(t["rgba8"], t["first_prim"], t["n_prims"], rt.TEX_MAP_PLANAR_XZ, t["scale"])
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 20; 10 for configs 2 and 4)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps (default: 3; 2 for configs 2 and 4)")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(WORKLOADS))
     ap.add_argument("--mode", choices=["megakernel", "wavefront", "nested"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true",
+                    help="skip the untimed extras (cold first launch, wavefront, strict math, traversal tallies): "
+                         "for profiler passes, where every launch of the process is averaged")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo with --rehearse-on-device lets N ranks share one GPU "
                          "to rehearse the N > 1 control flow (not a measurement)")
@@ -96,6 +184,12 @@ def main() -> None:
     ap.add_argument("--images-in-flight", type=int, default=0,
                     help="accumulation images per rank (default: 2 when N > 1, else 1)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.config]
+    heavy = args.config in (2, 4)
+    if args.steps <= 0:
+        args.steps = 10 if heavy else 20
+    if args.warmup < 0:
+        args.warmup = 2 if heavy else 3
 
     import numpy as np
     import torch
@@ -124,9 +218,11 @@ def main() -> None:
 
     mode = {"megakernel": rt.MODE_MEGAKERNEL, "wavefront": rt.MODE_WAVEFRONT,
             "nested": rt.MODE_MEGAKERNEL_NESTED}[args.mode]
-    ubo = rt.make_ubo(WIDTH, HEIGHT, SPP, BOUNCES)
-    spheres = rt.default_scene()
+    WIDTH, HEIGHT, SPP, BOUNCES = wl["w"], wl["h"], wl["spp"], wl["bounces"]
+    scene = build_scene(rt, np, wl)
+    ubo, spheres = scene["ubo"], scene["spheres"]
     n_spheres = spheres.shape[0]
+    frames_per_step = wl["frames"] if wl["scaling"] == "strong" else world   # over all ranks
 
     # the accumulation images live in torch tensors so RCCL can reduce them in place
     n_buf = args.images_in_flight if args.images_in_flight > 0 else (2 if world > 1 else 1)
@@ -136,12 +232,20 @@ def main() -> None:
         a = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
         rr = rt.Renderer(WIDTH, HEIGHT, mode=mode, flags=0, device=local_rank,
                          stream=stream.cuda_stream, accum_buffer=a.data_ptr())
-        rr.set_params(ubo)
-        rr.set_spheres(spheres)
+        apply_scene(rr, rt, scene)
         accums.append(a)
         renderers.append(rr)
     in_flight = [False] * n_buf
     pending = [None] * n_buf
+
+    # configs[3]: the terrain's vertices for eight phases of its motion, resident on the device
+    # before the timed region; every step rebuilds the LBVH from one of them
+    terrain = None
+    if wl["scene"] == "terrain":
+        idx = torch.from_numpy(scene["mesh"][1].view(np.int32)).to(dev)
+        verts = [torch.from_numpy(rt.terrain_mesh(709, phase=0.15 * k)[0]).to(dev) for k in range(8)]
+        terrain = dict(idx=idx, verts=verts, n_v=verts[0].shape[0], n_t=idx.shape[0], mat=scene["mesh"][2],
+                       build_ms=0.0, builds=0)
 
     rehearsal = world > 1 and args.backend == "gloo"
     small = torch.device("cpu") if rehearsal else dev   # where the scalar all-reduces live
@@ -173,7 +277,11 @@ def main() -> None:
         k = i % n_buf
         retire(k)
         accums[k].zero_()
-        first, count, stride = frame_partition(i * world, world, rank, world)
+        if terrain is not None:
+            v = terrain["verts"][i % len(terrain["verts"])]
+            renderers[k].set_mesh_device(v.data_ptr(), terrain["n_v"], terrain["idx"].data_ptr(), terrain["n_t"],
+                                         terrain["mat"])
+        first, count, stride = frame_partition(i * frames_per_step, frames_per_step, rank, world)
         renderers[k].render(first, count, stride)
         pending[k] = begin_sum(accums[k])
         in_flight[k] = True
@@ -192,6 +300,12 @@ def main() -> None:
         st = [rr.stats() for rr in renderers]
         return sum(s.rays for s in st), sum(s.total_render_ms for s in st)
 
+    # cold first frame of a context (cost probe + unordered tiles), reported beside the steady state
+    cold_ms = None
+    if world == 1 and not args.no_side_runs:
+        step(0)
+        fence()
+        cold_ms = renderers[0].stats().last_render_ms
     for i in range(args.warmup):
         step(i)
     fence()
@@ -205,21 +319,36 @@ def main() -> None:
 
     rays = float(rays1 - rays0)
     kernel_ms = float(ms1 - ms0)
+    st_last = renderers[0].stats()
 
-    # configs[1] asks for "megakernel vs wavefront": time a few frames of the other
-    # organisation outside the timed region (rank 0 of a single-GPU run only)
-    other_ms = None
-    if world == 1 and args.mode == "megakernel":
-        with rt.Renderer(WIDTH, HEIGHT, mode=rt.MODE_WAVEFRONT, device=local_rank) as wf:
-            wf.set_params(ubo)
-            wf.set_spheres(spheres)
-            wf.render(0, 1, 1)
-            wf.stats()
-            t = []
-            for f in range(1, 4):
-                wf.render(f, 1, 1)
-                t.append(wf.stats().last_render_ms)
-            other_ms = sorted(t)[1]
+    # outside the timed region, rank 0 of a single-GPU run only: the other kernel organisation
+    # (configs[1] asks for "megakernel vs wavefront"), the bit-exact strict-math launch, and for
+    # LBVH scenes the traversal tallies that price a path segment in bytes
+    other_ms = strict_ms = None
+    bytes_per_segment = nodes_per_seg = prims_per_seg = None
+    if world == 1 and args.mode == "megakernel" and not args.no_side_runs:
+        def side(mode_, flags, frames=3):
+            with rt.Renderer(WIDTH, HEIGHT, mode=mode_, flags=flags, device=local_rank) as x:
+                apply_scene(x, rt, scene)
+                x.render(0, wl["frames"], 1)
+                x.stats()
+                t = []
+                for f in range(1, frames + 1):
+                    x.render(f * wl["frames"], wl["frames"], 1)
+                    t.append(x.stats().last_render_ms)
+                return sorted(t)[len(t) // 2], x.stats()
+        if args.config in (0, 1, 2, 3):
+            other_ms, _ = side(rt.MODE_WAVEFRONT, 0, 3 if args.config != 2 else 1)
+        strict_ms, _ = side(rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH, 3 if not heavy else 1)
+        if wl["scene"] in ("grid", "terrain"):
+            with rt.Renderer(WIDTH, HEIGHT, flags=rt.FLAG_COUNT_TRAVERSAL, device=local_rank) as x:
+                probe = dict(scene)
+                probe["ubo"] = rt.make_ubo(WIDTH, HEIGHT, 2, BOUNCES)
+                apply_scene(x, rt, probe)
+                x.render(0, 1, 1)
+                s = x.stats()
+                nodes_per_seg = s.bvh_nodes_visited / max(s.rays, 1)
+                prims_per_seg = s.bvh_spheres_tested / max(s.rays, 1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=small)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,11 +360,97 @@ def main() -> None:
         total_rays = rays
 
     if rank == 0:
-        samples = float(WIDTH * HEIGHT * SPP * args.steps)  # per GPU
-        launch_ms = kernel_ms / max(args.steps, 1)          # rank 0's render launches, HIP events
-        flops = algorithmic_flops(rays, samples, n_spheres) / max(args.steps, 1)
-        achieved = flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-        traffic, traffic_src, pmc = pmc_traffic_bytes() if args.mode == "megakernel" else (None, None, {})
+        steps = max(args.steps, 1)
+        my_frames = frame_partition(0, frames_per_step, 0, world)[1]
+        samples = float(WIDTH * HEIGHT * SPP * my_frames * steps)      # rank 0's
+        launch_ms = kernel_ms / steps                                  # rank 0's render launches, HIP events
+        pmc = pmc_entry(args.config) if args.mode == "megakernel" else {}
+        cfg = {
+            "workload": wl["text"],
+            "mode": args.mode,
+            "math": "fast (hardware transcendental, sqrt and rcp units in sampling and distances; "
+                    "hit decisions and primary rays exact)",
+            "parallelism": f"frame-split x{world}" + (" + RCCL reduce overlapped with the next step"
+                                                      if world > 1 else "") +
+                           (" [REHEARSAL: gloo on host copies, ranks share a device -- not a measurement]"
+                            if rehearsal else ""),
+            "ms_per_launch": launch_ms,
+            "rays_per_step": total_rays / steps,
+            "tile_order": "warm: every timed launch runs its tiles heaviest-first by the costs the previous "
+                          "launch of the same view measured (progressive rendering repeats the view)",
+            "cold_first_launch_ms": cold_ms,
+            "strict_math_ms_per_launch": strict_ms,
+            "wavefront_ms_per_launch": other_ms,
+        }
+        if args.config == 1:   # names kept from the first round's line
+            cfg["ms_per_frame_1080p_64spp"] = launch_ms
+            cfg["rays_per_frame"] = rays / steps
+            cfg["wavefront_ms_per_frame_1080p_64spp"] = other_ms
+            cfg["strict_ms_per_frame"] = strict_ms
+        if terrain is not None:
+            cfg["lbvh_build_ms"] = st_last.last_build_ms
+            cfg["trace_ms"] = launch_ms
+            cfg["lbvh_height"] = st_last.bvh_height
+            cfg["note"] = ("value = segments / wall time of rebuild + trace per step; vertices and indices are "
+                           "device-resident (rt_set_mesh_device), so no host-device copy is inside a step")
+        if wl["scene"] in ("grid", "terrain"):
+            # algorithmic bytes of a path segment through the LBVH: 64-byte nodes, 16-byte spheres
+            # or 48-byte triangles, 64 bytes of material and geometry on a hit
+            prim_bytes = 48.0 if wl["scene"] == "terrain" else 16.0
+            hit_frac = max(rays - samples, 0.0) / max(rays, 1.0)
+            bytes_per_segment = 64.0 * nodes_per_seg + prim_bytes * prims_per_seg + 64.0 * hit_frac \
+                if nodes_per_seg is not None else None
+            kernel = "k_mega_sched<fast>" if args.mode == "megakernel" else args.mode
+            if bytes_per_segment is not None:
+                alg_bytes = bytes_per_segment * rays / steps + 44.0 * WIDTH * HEIGHT * my_frames
+                achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+            else:
+                alg_bytes, achieved = None, None
+            roof = {
+                "bound": "hbm",
+                "kernel": kernel,
+                "achieved": achieved,
+                "peak": PEAK_HBM_GBS,
+                "unit": "GB/s",
+                "frac": achieved / PEAK_HBM_GBS if achieved is not None else None,
+                "traffic": pmc.get("hbm_bytes_per_launch"),
+                "traffic_source": pmc.get("source"),
+                "launch_ms": launch_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_segment": bytes_per_segment,
+                "nodes_per_segment": nodes_per_seg,
+                "primitives_tested_per_segment": prims_per_seg,
+                "frac_of_l2_peak": achieved / PEAK_L2_GBS if achieved is not None else None,
+                "binds": "neither bandwidth: the tree's working set is served from L1/L2 and the launch waits on the "
+                         "latency of dependent node fetches; see valu_instructions_per_simd_cycle and "
+                         "valu_lane_utilisation (committed counter passes)",
+                "valu_instructions_per_simd_cycle": pmc.get("valu_instructions_per_simd_cycle"),
+                "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
+                "l2_hit_rate": pmc.get("l2_hit_rate"),
+            }
+        else:
+            flops = algorithmic_flops(rays, samples, n_spheres) / steps
+            achieved = flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+            roof = {
+                # Branchy FP32 vector work with no dense contraction: the kernel issues no MFMA, and
+                # the bound that applies is FP32 vector issue (the same 157.3 TFLOP/s as the f32 MFMA peak).
+                "bound": "valu",
+                "kernel": {"megakernel": "k_mega_regen<fast,brute>", "nested": "k_mega_nested<fast,brute>",
+                           "wavefront": "wavefront stages"}[args.mode],
+                "achieved": achieved,
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "traffic": pmc.get("hbm_bytes_per_launch"),
+                "traffic_source": pmc.get("source"),
+                # from the same committed counter passes: wave-level VALU instructions per SIMD-cycle
+                # over what a SIMD was measured to issue, and share of the 64 lanes active per instruction
+                "valu_issue_frac": pmc.get("valu_issue_frac"),
+                "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
+                "launch_ms": launch_ms,
+                "algorithmic_flops_per_launch": flops,
+                "note": "FP32 vector issue bound (no MFMA in a path tracer); HBM traffic is ~50 B/pixel/frame",
+            }
         out = {
             "metric": "Mrays/sec (all bounces)",
             "value": total_rays / elapsed / 1e6,
@@ -243,54 +458,18 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": wl["scaling"],
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": f"reference default scene (3 spheres, main.cpp:517-538), {WIDTH}x{HEIGHT}, "
-                            f"{SPP} spp/frame, maxBounce {BOUNCES}, 1 frame per GPU per step "
-                            "(BASELINE.json configs[1])",
-                "mode": args.mode,
-                "math": "fast (hardware transcendental, sqrt and rcp units in sampling and distances; "
-                        "hit decisions and primary rays exact)",
-                "parallelism": f"frame-split x{world}" + (" + RCCL reduce overlapped with the next frame"
-                                                          if world > 1 else "") +
-                               (" [REHEARSAL: gloo on host copies, ranks share a device -- not a measurement]"
-                                if rehearsal else ""),
-                "ms_per_frame_1080p_64spp": launch_ms,
-                "rays_per_frame": rays / max(args.steps, 1),
-                "wavefront_ms_per_frame_1080p_64spp": other_ms,
-            },
-            "roofline": {
-                # the contract's two bounds are "hbm" and "mfma": this is the compute one.  The kernel
-                # issues no MFMA (there is no dense contraction in a path tracer); its arithmetic is
-                # FP32 vector work, priced against the f32 peak, which is the same 157.3 TFLOP/s
-                "bound": "mfma",
-                "compute_unit": "valu",
-                "kernel": {"megakernel": "k_mega_regen<fast,brute>", "nested": "k_mega_nested<fast,brute>",
-                           "wavefront": "wavefront stages"}[args.mode],
-                "achieved": achieved,
-                "peak": PEAK_FP32_VALU_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                # from the same committed counter passes: wave-level VALU instructions per SIMD-cycle
-                # over what a SIMD was measured to issue, and share of the 64 lanes active per instruction
-                "valu_issue_frac": pmc.get("valu_issue_frac"),
-                "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
-                "launch_ms": launch_ms,
-                "algorithmic_flops_per_launch": flops,
-                "note": "branchy FP32 vector work, no dense contraction: priced against the FP32 "
-                        "vector peak (= the f32 MFMA peak); HBM traffic is ~50 B/pixel/frame",
-            },
+            "config": cfg,
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(ubo, spheres, threads)
+            out["cpu_baseline"] = cpu_baseline(wl, scene, threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

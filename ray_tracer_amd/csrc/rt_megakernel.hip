@@ -132,11 +132,12 @@ __device__ __forceinline__ uint32_t tile_thread() {
 
 // per-wave epilogue: path segments into the ray counter, slowest pixel into the tile's cost
 // (a probe launch records costs and nothing else)
+template <bool PROBE>
 __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint32_t nrays) {
   const uint32_t wsum = wave_sum_u32(nrays);
   const uint32_t wmax = wave_max_u32(nrays);
   if ((threadIdx.x & 63u) == 0) {
-    if (wsum && !O.probe) atomicAdd(O.rays, (unsigned long long)wsum);
+    if (wsum && !PROBE) atomicAdd(O.rays, (unsigned long long)wsum);
     if (O.tile_cost) atomicMax(O.tile_cost + tile, wmax);
   }
 }
@@ -144,9 +145,10 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
 // End of one frame of one pixel in the tile kernels: the accumulation value and the 8-bit
 // pixel are read here, blended (frame_epilogue) and written back, instead of being carried in
 // five registers through a loop that needs them once per frame.  A probe launch writes nothing.
+template <bool PROBE>
 __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, size_t pix, f3 total,
                                           float frame_f) {
-  if (O.probe) return;
+  if (PROBE) return;
   float4 acc = O.accum[pix];
   uchar4 img = O.rgba8[pix];
   frame_epilogue(P, total, frame_f, O.linear_accum, acc, img);
@@ -165,7 +167,7 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
           total = total + light; \
           ++s; \
           if (s >= P.n_spp) { \
-            end_frame(P, O, pix, total, (float)frame); \
+            end_frame<PROBE>(P, O, pix, total, (float)frame); \
             ++fi; \
             if (fi >= F.count) { \
               active = false; \
@@ -196,7 +198,9 @@ constexpr int regen_waves(bool strict, bool tex, int form) {
   if (form != kRegenBatched || strict) return RT_MEGA_WAVES;
   return tex ? RT_REGEN_BATCHED_TEX_WAVES : RT_REGEN_BATCHED_WAVES;
 }
-template <bool STRICT, bool BVH, bool EXT, bool APPROX, int FORM>
+// PROBE: a cost probe (its own instantiation, so that profiles list it apart from the frames):
+// traces like any launch but writes the per-tile costs and nothing else.
+template <bool STRICT, bool BVH, bool EXT, bool APPROX, int FORM, bool PROBE = false>
 __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
   constexpr bool DIEL = EXT && !APPROX;
   extern __shared__ int stack[];  // BVH: [entry][thread], S.stack_entries entries (sized by the launch)
@@ -346,16 +350,16 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
           }
         }
       }
-      if (!O.probe) {
+      if (!PROBE) {
         O.accum[pix] = acc;
         O.rgba8[pix] = img;
       }
     }
 #ifndef RT_MEASURE_TIMELINE
-    if (!O.probe) O.ids[pix] = id0;
+    if (!PROBE) O.ids[pix] = id0;
 #endif
   }
-  tally_wave(O, tile, nrays);
+  tally_wave<PROBE>(O, tile, nrays);
 #ifdef RT_MEASURE_TIMELINE
   // measurement build (tools/wave_timeline.py): per-wave begin and end in 100 MHz ticks,
   // segments traced and the slowest lane's segments go where the primary ids would
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
 #define RT_SCHED_TALLY(step, n)
 #endif
 
-template <bool STRICT, bool EXT, bool APPROX>
+template <bool STRICT, bool EXT, bool APPROX, bool PROBE = false>
 __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   // [entry][thread], S.stack_entries entries: the launch sizes it by the height of the tree
   // (a 16-level tree leaves room for twice the waves a fixed 32-entry stack would)
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1)
         total = total + light;
         ++s;
         if (s >= P.n_spp) {
-          end_frame(P, O, pix, total, (float)frame);
+          end_frame<PROBE>(P, O, pix, total, (float)frame);
           ++fi;
           if (fi >= F.count) {
             active = false;
@@ -494,11 +498,11 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1)
       if (active) {
         search_begin<DIEL>(S, o, d, skip, Q);
       } else {
-        if (!O.probe) O.ids[pix] = id0;
+        if (!PROBE) O.ids[pix] = id0;
       }
     }
   }
-  tally_wave(O, tile, nrays);
+  tally_wave<PROBE>(O, tile, nrays);
 }
 
 template <bool STRICT, bool BVH, bool EXT, bool APPROX>
@@ -539,9 +543,14 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
   const size_t block_stack = BVH ? (size_t)S.stack_entries * 256u * sizeof(int) : 0;
   if (nested)
     hipLaunchKernelGGL((k_mega_nested<STRICT, BVH, EXT, APPROX>), grid, block, block_stack, stream, P, S, F, O);
+  else if (BVH && sched && O.probe)
+    hipLaunchKernelGGL((k_mega_sched<STRICT, EXT, APPROX, true>), wave_tiles, wave_block,
+                       (size_t)S.stack_entries * kTileBlock * sizeof(int), stream, P, S, F, O);
   else if (BVH && sched)
     hipLaunchKernelGGL((k_mega_sched<STRICT, EXT, APPROX>), wave_tiles, wave_block,
                        (size_t)S.stack_entries * kTileBlock * sizeof(int), stream, P, S, F, O);
+  else if (BVH && O.probe)
+    hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain, true>), tiles, block, block_stack, stream, P, S, F, O);
   else if (BVH)
     hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain>), tiles, block, block_stack, stream, P, S, F, O);
   else {
@@ -554,7 +563,11 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     Outputs Q = O;
     Q.chain_ranks = (O.n_tiles + chain_div - 1u) / chain_div;
     constexpr bool B = !BVH;  // keeps the BVH instantiations of the brute-force forms out of the library
-    if (form == kRegenMixed)
+    if (O.probe && form == kRegenBatched)
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain, true>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
+    else if (O.probe)
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain, true>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
+    else if (form == kRegenMixed)
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenMixed : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else if (form == kRegenBatched)
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);

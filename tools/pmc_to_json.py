@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Folds the pmc_cfgN.txt summaries of tools/profile_configs.sh into profiles/pmc_latest.json,
+the file bench.py reads its `traffic` and counter ratios from.
+
+    python tools/pmc_to_json.py profiles/r2 [tag shown in the source strings]
+
+Per workload and per launch of its dominant kernel (the variant with the most dispatches):
+  hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; FETCH_SIZE reads half the
+  bytes of wide coalesced reads on gfx950), cycles = GRBM_GUI_ACTIVE / 8 XCDs,
+  valu_instructions_per_simd_cycle = SQ_INSTS_VALU / (1024 SIMDs * cycles),
+  valu_lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU),
+  waves_per_simd = 4 * SQ_WAVE_CYCLES / (1024 * cycles)   (the counter ticks every 4 cycles),
+  wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES, l2_hit_rate = TCC_HIT / (TCC_HIT + TCC_MISS),
+  l1_hit_rate = 1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES.
+"""
+import json
+import os
+import re
+import sys
+
+src = sys.argv[1]
+ISSUE_CAPACITY = 0.40   # wave-level VALU instructions one SIMD issues per cycle (tools/micro/issue_cost.hip)
+
+
+def parse(path):
+    kernels, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" ") and line.strip() and not line.startswith("#"):
+            cur = line.strip()
+            kernels[cur] = {}
+        elif cur and line.startswith("  "):
+            m = re.match(r"\s+(\S+)\s+total\s+(\S+)\s+per-dispatch\s+(\S+)\s+dispatches\s+(\d+)", line)
+            if m:
+                kernels[cur][m.group(1)] = (float(m.group(3)), int(m.group(4)))
+    return kernels
+
+
+out = {"configs": {}}
+for c in ("0", "1", "2", "3", "4"):
+    path = os.path.join(src, f"pmc_cfg{c}.txt")
+    if not os.path.exists(path):
+        continue
+    kernels = parse(path)
+    if not kernels:
+        continue
+    name = max(kernels, key=lambda k: max((v[1] for v in kernels[k].values()), default=0))
+    k = {n: v[0] for n, v in kernels[name].items()}
+    e = {"kernel": name, "source": f"{path} (rocprofv3 --pmc passes over `bench.py --config {c} --steps 4 "
+                                   "--no-side-runs`, one run per pass; FETCH_SIZE doubled, gfx950)"}
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        e["FETCH_SIZE_KB_per_launch"] = k["FETCH_SIZE"]
+        e["WRITE_SIZE_KB_per_launch"] = k["WRITE_SIZE"]
+        e["hbm_bytes_per_launch"] = int((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
+    if "GRBM_GUI_ACTIVE" in k:
+        cycles = k["GRBM_GUI_ACTIVE"] / 8.0
+        e["cycles_per_launch"] = cycles
+        if "SQ_INSTS_VALU" in k:
+            e["valu_instructions_per_launch"] = k["SQ_INSTS_VALU"]
+            e["valu_instructions_per_simd_cycle"] = round(k["SQ_INSTS_VALU"] / (1024 * cycles), 4)
+            e["valu_issue_capacity_per_simd_cycle"] = ISSUE_CAPACITY
+            e["valu_issue_frac"] = round(k["SQ_INSTS_VALU"] / (1024 * cycles) / ISSUE_CAPACITY, 3)
+        if "SQ_WAVE_CYCLES" in k:
+            e["waves_per_simd"] = round(4 * k["SQ_WAVE_CYCLES"] / (1024 * cycles), 2)
+    if "SQ_THREAD_CYCLES_VALU" in k and "SQ_ACTIVE_INST_VALU" in k:
+        e["valu_lane_utilisation"] = round(k["SQ_THREAD_CYCLES_VALU"] / (64 * k["SQ_ACTIVE_INST_VALU"]), 3)
+    if "SQ_WAIT_ANY" in k and "SQ_WAVE_CYCLES" in k:
+        e["wait_share_of_wave_cycles"] = round(k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"], 3)
+    if "TCC_HIT_sum" in k and "TCC_MISS_sum" in k:
+        e["l2_hit_rate"] = round(k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]), 3)
+    if "TCP_TCC_READ_REQ_sum" in k and "TCP_TOTAL_CACHE_ACCESSES_sum" in k:
+        e["l1_hit_rate"] = round(1 - k["TCP_TCC_READ_REQ_sum"] / k["TCP_TOTAL_CACHE_ACCESSES_sum"], 3)
+    out["configs"][c] = e
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(src.rstrip("/"))), "pmc_latest.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
