@@ -354,7 +354,9 @@ __device__ __forceinline__ int delta(const uint32_t *__restrict__ codes, int n, 
 __global__ __launch_bounds__(kThreads) void k_hierarchy(const uint32_t *__restrict__ codes, int n,
                                                         int *__restrict__ left, int *__restrict__ right,
                                                         int *__restrict__ parent,
-                                                        int *__restrict__ leaf_parent) {
+                                                        int *__restrict__ leaf_parent,
+                                                        int *__restrict__ range_first,
+                                                        int *__restrict__ range_count) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n - 1) return;
   if (i == 0) parent[0] = -1;
@@ -379,12 +381,15 @@ __global__ __launch_bounds__(kThreads) void k_hierarchy(const uint32_t *__restri
   const int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
   left[i] = lc;
   right[i] = rc;
+  range_first[i] = lo;  // the node covers sorted positions lo .. hi
+  range_count[i] = hi - lo + 1;
   if (lc < 0) leaf_parent[gamma] = i; else parent[lc] = i;
   if (rc < 0) leaf_parent[gamma + 1] = i; else parent[rc] = i;
 }
 
 struct RefitView {
   const int *left, *right, *parent;
+  const int *range_first, *range_count;  // sorted positions under each internal node
   const uint32_t *sorted_prim;        // sorted position -> original index
   const float4 *leaf_lo, *leaf_hi;    // by original index
   uint32_t *stamp;                    // pass in which a node was finished, 0 = not yet
@@ -398,19 +403,29 @@ __device__ __forceinline__ bool child_ready(const RefitView &v, int c, uint32_t 
   const uint32_t s = v.stamp[c];
   return s != 0u && s < pass;
 }
+// an internal node over at most kLeafMaxPrims primitives is referenced as one leaf (its own
+// record is then never visited); the root stays a node
+__device__ __forceinline__ void fold_small_subtree(const RefitView &v, int &c, float &height) {
+  if (c > 0 && v.range_count[c] <= kLeafMaxPrims) {
+    c = make_leaf_ref((uint32_t)v.range_first[c], (uint32_t)v.range_count[c]);
+    height = 0.f;
+  }
+}
 // For a leaf of an oversized sphere, c is rewritten to kNullLeaf.
 __device__ __forceinline__ void child_box(const RefitView &v, int &c, float4 &lo, float4 &hi,
                                           float &height) {
   if (c < 0) {
-    const uint32_t prim = v.sorted_prim[~c];
+    const uint32_t pos = (uint32_t)~c;
+    const uint32_t prim = v.sorted_prim[pos];
     lo = v.leaf_lo[prim];
     hi = v.leaf_hi[prim];
     height = 0.f;
-    if (lo.w != 0.f) c = kNullLeaf;
+    c = lo.w != 0.f ? kNullLeaf : make_leaf_ref(pos, 1u);
   } else {
     lo = v.box_lo[c];
     hi = v.box_hi[c];
     height = lo.w;
+    fold_small_subtree(v, c, height);
   }
 }
 // writes node i from its two children's boxes; returns its own box in (lo, hi, height)
@@ -454,8 +469,10 @@ __global__ __launch_bounds__(kThreads) void k_refit(RefitView v, uint32_t pass) 
     child_box(v, sib, sl, sh, sht);
     float4 nlo, nhi;
     float nh;
-    if (i_is_left) finish_node(v, p, pc0, sib, lo, hi, height, sl, sh, sht, pass, nlo, nhi, nh);
-    else finish_node(v, p, sib, pc1, sl, sh, sht, lo, hi, height, pass, nlo, nhi, nh);
+    int self = i;
+    fold_small_subtree(v, self, height);
+    if (i_is_left) finish_node(v, p, self, sib, lo, hi, height, sl, sh, sht, pass, nlo, nhi, nh);
+    else finish_node(v, p, sib, self, sl, sh, sht, lo, hi, height, pass, nlo, nhi, nh);
     lo = nlo; hi = nhi; height = nh;
     i = p;
   }
@@ -480,6 +497,7 @@ struct Lbvh::Work {
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr};
   uint32_t *hist = nullptr, *scan_sums = nullptr, *stamp = nullptr, *cbounds = nullptr;
   int *left = nullptr, *right = nullptr, *parent = nullptr, *leaf_parent = nullptr;
+  int *range_first = nullptr, *range_count = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -550,7 +568,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     const size_t f4 = align256((size_t)n * sizeof(float4)), u4 = align256((size_t)n * sizeof(uint32_t));
     const size_t hist = align256((size_t)256 * nblk * sizeof(uint32_t));
     const size_t sums = align256(((size_t)256 * nblk / kScanTile + 2) * sizeof(uint32_t));
-    const size_t total = 5 * f4 + 9 * u4 + hist + sums + 256;
+    const size_t total = 5 * f4 + 11 * u4 + hist + sums + 256;
     BVH_HIP(hipMalloc((void **)&work->slab, total));
     char *p = work->slab;
     auto take = [&](size_t bytes) { char *q = p; p += bytes; return q; };
@@ -568,6 +586,8 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     work->right = (int *)take(u4);
     work->parent = (int *)take(u4);
     work->leaf_parent = (int *)take(u4);
+    work->range_first = (int *)take(u4);
+    work->range_count = (int *)take(u4);
     work->hist = (uint32_t *)take(hist);
     work->scan_sums = (uint32_t *)take(sums);
     work->cbounds = (uint32_t *)take(256);
@@ -687,10 +707,11 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
   if (n >= 2) {
     const uint32_t blocks_i = (n - 1 + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_hierarchy, dim3(blocks_i), dim3(kThreads), 0, stream, w.keys[cur], (int)n,
-                       w.left, w.right, w.parent, w.leaf_parent);
+                       w.left, w.right, w.parent, w.leaf_parent, w.range_first, w.range_count);
     BVH_HIP(hipMemsetAsync(w.stamp, 0, (size_t)(n - 1) * sizeof(uint32_t), stream));
     RefitView rv;
     rv.left = w.left; rv.right = w.right; rv.parent = w.parent;
+    rv.range_first = w.range_first; rv.range_count = w.range_count;
     rv.sorted_prim = sorted_prim;
     rv.leaf_lo = w.leaf_lo; rv.leaf_hi = w.leaf_hi;
     rv.stamp = w.stamp; rv.box_lo = w.box_lo; rv.box_hi = w.box_hi;

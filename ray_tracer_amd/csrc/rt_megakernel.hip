@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1)
     } else if (w_leaf >= w_shade) {
       RT_SCHED_TALLY(2, n_leaf);
       if (want_leaf) {
-        leaf_candidate<DIEL>(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        leaf_range<DIEL>(S, Q.node, o, d, Q.a, skip, Q.best);
         Q.node = search_pop<kTileBlock>(Q, stack);
       }
     } else {

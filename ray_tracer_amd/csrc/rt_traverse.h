@@ -61,6 +61,15 @@ __device__ __forceinline__ void leaf_candidate(const Scene &S, int pos, f3 o, f3
   }
 }
 
+// every primitive of a leaf reference (a run of sorted positions, see make_leaf_ref)
+template <bool DIEL = false, bool APPROX>
+__device__ __forceinline__ uint32_t leaf_range(const Scene &S, int ref, f3 o, f3 d, float a, int skip,
+                                               Closest<APPROX> &C) {
+  const uint32_t first = leaf_ref_first(ref), count = leaf_ref_count(ref);
+  for (uint32_t k = 0; k < count; ++k) leaf_candidate<DIEL>(S, (int)(first + k), o, d, a, skip, C);
+  return count;
+}
+
 // the oversized spheres kept out of the tree, tested before it
 template <bool DIEL, bool APPROX>
 __device__ __forceinline__ void large_candidates(const Scene &S, f3 o, f3 d, float a, int skip,
@@ -109,15 +118,15 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
       int c0 = nd.child0, c1 = nd.child1;
       if (t0 < __builtin_inff() && c0 < 0) {
         if (c0 != kNullLeaf) {
-          leaf_candidate<DIEL>(S, ~c0, o, d, a, skip, C);
-          if constexpr (COUNT) ++*n_prims;
+          const uint32_t tested = leaf_range<DIEL>(S, c0, o, d, a, skip, C);
+          if constexpr (COUNT) *n_prims += tested;
         }
         t0 = __builtin_inff();
       }
       if (t1 < __builtin_inff() && c1 < 0) {
         if (c1 != kNullLeaf) {
-          leaf_candidate<DIEL>(S, ~c1, o, d, a, skip, C);
-          if constexpr (COUNT) ++*n_prims;
+          const uint32_t tested = leaf_range<DIEL>(S, c1, o, d, a, skip, C);
+          if constexpr (COUNT) *n_prims += tested;
         }
         t1 = __builtin_inff();
       }
@@ -170,7 +179,7 @@ constexpr int kSearchOver = (int)kNullLeaf;  // never a real child reference
 
 template <bool APPROX>
 struct Search {
-  int node;  // >= 0 inner node, kSearchOver, otherwise ~leaf position
+  int node;  // >= 0 inner node, kSearchOver, otherwise a leaf reference
   int sp;
   float a;
   f3 inv_d, oi;  // 1 / d and o / d

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene 
       }
     } else if (w_leaf >= w_next) {
       if (want_leaf) {
-        leaf_candidate<DIEL>(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        leaf_range<DIEL>(S, Q.node, o, d, Q.a, skip, Q.best);
         Q.node = search_pop(Q, stack);
       }
     } else if (want_next) {
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params 
       }
     } else if (w_leaf >= w_shade) {
       if (want_leaf) {
-        leaf_candidate<DIEL>(S, ~Q.node, o, d, Q.a, skip, Q.best);
+        leaf_range<DIEL>(S, Q.node, o, d, Q.a, skip, Q.best);
         Q.node = search_pop(Q, stack);
       }
     } else if (want_shade) {
