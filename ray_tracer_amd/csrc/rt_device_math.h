@@ -74,6 +74,20 @@ __device__ __forceinline__ uint32_t pcg_next(uint32_t &s) {
 // float(u) / 4294967295.0: the literal is 2^32 in fp32, so this is an exact scale
 __device__ __forceinline__ float pcg_float(uint32_t &s) { return (float)pcg_next(s) * 0x1p-32f; }
 
+// The k-th state after s: the LCG step s -> s * A + C composed k times is s * A^k + C_k, so
+// the seven states a hit bounce consumes are seven independent multiply-adds instead of a chain
+// (same values; the draws no longer wait for one another).
+__device__ __forceinline__ uint32_t pcg_jump(uint32_t s, int k) {
+  constexpr uint32_t A[8] = {1u, 747796405u, 4201498105u, 3399858189u, 2200120369u, 2975532453u, 1226092713u, 371291773u};
+  constexpr uint32_t C[8] = {0u, 2891336453u, 1192405134u, 568162667u, 878960812u, 3598456993u, 3109587930u, 457671207u};
+  return s * A[k] + C[k];
+}
+// randomValue of a state that has already been advanced
+__device__ __forceinline__ float pcg_output_float(uint32_t s) {
+  uint32_t r = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+  return (float)((r >> 22) ^ r) * 0x1p-32f;
+}
+
 // ---- strict polynomial kernels ---------------------------------------------
 namespace pm {
 

@@ -390,14 +390,8 @@ __device__ __forceinline__ f3 environment(const Params &P, f3 d) {
 }
 
 // ---- scatter (ray_tracing.comp:199-213) ---------------------------------------------
-// randomValueNormalDistribution (ray_tracing.comp:121-125): theta draw before rho draw
-template <bool STRICT>
-__device__ __forceinline__ float normal_draw(uint32_t &rng) {
-  using M = Math<STRICT>;
-  float u1 = pcg_float(rng);
-  float u2 = pcg_float(rng);
-  return M::sqrt(M::neg2log(u2)) * M::box_cos(u1);
-}
+// randomValueNormalDistribution (ray_tracing.comp:121-125) = sqrt(-2 log(u2)) * cos(2 pi u1) with
+// the theta draw u1 taken before the rho draw u2; evaluated inside scatter() below.
 
 // ---- albedo texture (extension; sampler state of vulkan_texture.cpp:77-95: LINEAR filter,
 // REPEAT addressing, one level) -----------------------------------------------------------
@@ -504,15 +498,21 @@ __device__ __forceinline__ float scatter(f3 p, f3 n, float smoothness, float4 m_
                                          f3 &light, f3 colour) {
   using M = Math<STRICT>;
   o = p;                                     // (:201)
-  float x = normal_draw<STRICT>(rng);        // randomDirection (:127-132)
-  float y = normal_draw<STRICT>(rng);
-  float z = normal_draw<STRICT>(rng);
+  // The bounce's seven draws (randomDirection: x(theta, rho) y(theta, rho) z(theta, rho), then the
+  // specular test) from seven independently computed states: same values as seven chained steps,
+  // but no draw waits for the one before it (1.5 % off the chain of a wave that runs alone).
+  const uint32_t s0 = rng;
+  rng = pcg_jump(s0, 7);
+  float x = M::sqrt(M::neg2log(pcg_output_float(pcg_jump(s0, 2)))) * M::box_cos(pcg_output_float(pcg_jump(s0, 1)));
+  float y = M::sqrt(M::neg2log(pcg_output_float(pcg_jump(s0, 4)))) * M::box_cos(pcg_output_float(pcg_jump(s0, 3)));
+  float z = M::sqrt(M::neg2log(pcg_output_float(pcg_jump(s0, 6)))) * M::box_cos(pcg_output_float(pcg_jump(s0, 5)));
+  const float u_spec = pcg_output_float(rng);
   f3 rd = M::normalize(mk3(x, y, z));
   f3 diffuse = M::normalize(n + rd);         // (:202)
   float dn2 = 2.0f * dot(n, d);              // reflect(I, N) = I - 2 dot(N, I) N (:203)
   f3 spec = mk3(__builtin_fmaf(-dn2, n.x, d.x), __builtin_fmaf(-dn2, n.y, d.y),
                 __builtin_fmaf(-dn2, n.z, d.z));
-  float is_spec = (specular_probability >= pcg_float(rng)) ? 1.0f : 0.0f;  // (:204-205)
+  float is_spec = (specular_probability >= u_spec) ? 1.0f : 0.0f;  // (:204-205)
   d = mix3(diffuse, spec, smoothness * is_spec);                          // (:206-207)
   f3 emitted = mk3(m_emission.x * m_emission.w, m_emission.y * m_emission.w,
                    m_emission.z * m_emission.w);                  // (:209-210)
