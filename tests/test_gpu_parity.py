@@ -1046,3 +1046,42 @@ def test_converged_image_fast_math_against_strict_math():
     assert int(d8.max()) <= 1
     assert abs(rays_f - rays_s) <= 1e-3 * rays_s
     assert p_seed < p - 6.0
+
+
+def test_headless_driver_multi_device_path(tmp_path):
+    """rt_headless --gpus N: one host thread and context per device, frames r, r+N, ..., one
+    ncclReduce of the accumulation images, resolve on device 0.  A one-GPU box can run the
+    whole path with N = 1 (--reduce: communicator of one rank, in-place reduce); its picture
+    must equal the library's own render + resolve, and the ranks' frame split is the one
+    test_frame_split_equals_sequential and the gloo test cover."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_headless")
+    if not os.path.exists(exe):
+        pytest.skip("rt_headless is not built (make -C ray_tracer_amd/csrc)")
+    out = str(tmp_path / "m.ppm")
+    w, h = 112, 80
+    res = subprocess.run([exe, "--width", str(w), "--height", str(h), "--samples", "3", "--bounces", "6",
+                          "--frames", "4", "--scene", "glass:200", "--gpus", "1", "--reduce", "--out", out],
+                         capture_output=True, text=True, timeout=180)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    sph, ior = rt.grid_spheres_scene_glass(200)
+    with rt.Renderer(w, h) as r:
+        r.set_params(rt.make_ubo(w, h, 3, 6))
+        r.set_spheres(sph)
+        r.set_dielectric(ior)
+        r.render(0, 4, 1)
+        r.resolve()
+        want, rays = r.read_rgba8(), int(r.stats().rays)
+    assert info["rays"] == rays and info["gpus"] == 1 and info["bvh_nodes"] == 199
+    data = open(out, "rb").read()
+    head = f"P6\n{w} {h}\n255\n".encode()
+    body = np.frombuffer(data[len(head):], dtype=np.uint8).reshape(h, w, 3)
+    assert np.array_equal(body, want[::-1, :, :3])
+    # asking for more devices than the box has is an error, not a crash
+    import torch
+    bad = subprocess.run([exe, "--width", "32", "--height", "32", "--gpus", str(torch.cuda.device_count() + 1)],
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "devices are visible" in bad.stderr
