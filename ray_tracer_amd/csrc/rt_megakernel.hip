@@ -26,6 +26,9 @@
 #ifndef RT_SCHED_WAVES
 #define RT_SCHED_WAVES 6  // waves per SIMD the untextured fast k_mega_sched is compiled for (80 VGPR; 3840x2160, 10k spheres / terrain: 5 waves 5.42 / 14.65 ms, 6: 5.35 / 14.52, 7: 5.37 / 14.89)
 #endif
+#ifndef RT_SCHED_EXT_WAVES
+#define RT_SCHED_EXT_WAVES 1  // the same for the fast k_mega_sched that carries the extensions (1: no cap, 93 VGPR)
+#endif
 #ifndef RT_REGEN_BATCHED_TEX_WAVES
 #define RT_REGEN_BATCHED_TEX_WAVES 6  // the textured batched loop (80 VGPR; 8K frame pair 30.1 ms, uncapped 32.3, 7 waves 31.3)
 #endif
@@ -160,6 +163,16 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
 // the environment for a path that escaped, sample sum, frame epilogue, next primary ray.
 // (A macro over the kernel's locals rather than a lambda: with a lambda the batched kernel,
 // which is compiled against a register cap, came out 4 % slower.)
+// The batched loops and k_mega_sched store a pixel's primary-hit id where it is found (first
+// segment of sample 0 of each frame, the last frame's store stays) instead of carrying it to
+// the end of the launch in a register.  The timeline build keeps its records in that array.
+#ifdef RT_MEASURE_TIMELINE
+#define RT_STORE_FIRST_ID(idx)
+#else
+#define RT_STORE_FIRST_ID(idx) \
+        if (!PROBE && s == 0 && b == 0) O.ids[(size_t)py * P.width + px] = (idx)
+#endif
+
 #define RT_END_PATHS() \
         if (active && ended != 0) { \
           if (ended == 1) light = fma3v(environment<STRICT>(P, d), colour, light); \
@@ -167,13 +180,12 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
           total = total + light; \
           ++s; \
           if (s >= P.n_spp) { \
-            end_frame<PROBE>(P, O, pix, total, (float)frame); \
+            end_frame<PROBE>(P, O, (size_t)py * P.width + px, total, (float)(F.first + fi * F.stride)); \
             ++fi; \
             if (fi >= F.count) { \
               active = false; \
             } else { \
-              frame += F.stride; \
-              rng = pixel_seed(P, px, py, frame); \
+              rng = pixel_seed(P, px, py, F.first + fi * F.stride); \
               total = mk3(0.f, 0.f, 0.f); \
               s = 0; \
             } \
@@ -224,13 +236,10 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
   const unsigned long long t_begin = wall_clock64();
 #endif
   if (px < P.width && py < P.height && F.count) {
-    const size_t pix = (size_t)py * P.width + px;
     const f3 base = pixel_direction(P, px, py);
-    int id0 = -1;
 
     uint32_t fi = 0;
-    uint32_t frame = F.first;
-    uint32_t rng = pixel_seed(P, px, py, frame);
+    uint32_t rng = pixel_seed(P, px, py, F.first);
     f3 total = mk3(0.f, 0.f, 0.f);
     int s = 0, b = 0;
     f3 o, d;
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
           if (active && ended == 0 && !has_hit) {
             const Hit h = closest_hit<BVH, APPROX, false, DIEL>(S, o, d, stack, skip);
             ++nrays;
-            if (s == 0 && b == 0) id0 = h.idx;
+            RT_STORE_FIRST_ID(h.idx);
             if (h.idx >= 0) {
               pending = h;
               has_hit = true;
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
           if (active && ended == 0) {
             const Hit h = closest_hit<BVH, APPROX, false, DIEL>(S, o, d, stack, skip);
             ++nrays;
-            if (s == 0 && b == 0) id0 = h.idx;
+            RT_STORE_FIRST_ID(h.idx);
             if (h.idx >= 0) {
               skip = shade_hit<STRICT, EXT, APPROX>(S, h, skip, rng, o, d, light, colour);
               ++b;
@@ -310,6 +319,9 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
     } else {
       // (this loop keeps the pixel's accumulation value and 8-bit colour in registers: with
       // the read-modify-write of end_frame inside it the chain of a lone wave is 12 % longer)
+      const size_t pix = (size_t)py * P.width + px;
+      int id0 = -1;
+      uint32_t frame = F.first;
       float4 acc = O.accum[pix];
       uchar4 img = O.rgba8[pix];
       bool active = true;
@@ -353,11 +365,11 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
       if (!PROBE) {
         O.accum[pix] = acc;
         O.rgba8[pix] = img;
+#ifndef RT_MEASURE_TIMELINE
+        O.ids[pix] = id0;
+#endif
       }
     }
-#ifndef RT_MEASURE_TIMELINE
-    if (!PROBE) O.ids[pix] = id0;
-#endif
   }
   tally_wave<PROBE>(O, tile, nrays);
 #ifdef RT_MEASURE_TIMELINE
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
 #endif
 
 template <bool STRICT, bool EXT, bool APPROX, bool PROBE = false>
-__global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
+__global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES : RT_SCHED_WAVES)) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   // [entry][thread], S.stack_entries entries: the launch sizes it by the height of the tree
   // (a 16-level tree leaves room for twice the waves a fixed 32-entry stack would)
   constexpr bool DIEL = EXT && !APPROX;
@@ -414,12 +426,9 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1)
   pixel_of_tile(tile, O.tiles_x, tile_thread<kTileBlock>(), px, py);
   uint32_t nrays = 0;
   bool active = px < P.width && py < P.height && F.count;
-  const size_t pix = active ? (size_t)py * P.width + px : 0;
   const f3 base = pixel_direction(P, px, py);
-  int id0 = -1;
   uint32_t fi = 0;
-  uint32_t frame = F.first;
-  uint32_t rng = pixel_seed(P, px, py, frame);
+  uint32_t rng = pixel_seed(P, px, py, F.first);
   f3 total = mk3(0.f, 0.f, 0.f);
   int s = 0, b = 0;
   f3 o, d;
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1)
       if (!want_shade) continue;
       const Hit h = Q.best.result();
       ++nrays;
-      if (s == 0 && b == 0) id0 = h.idx;
+      RT_STORE_FIRST_ID(h.idx);
       bool path_done;
       if (h.idx >= 0) {
         skip = shade_hit<STRICT, EXT, APPROX>(S, h, skip, rng, o, d, light, colour);
@@ -476,13 +485,12 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1)
         total = total + light;
         ++s;
         if (s >= P.n_spp) {
-          end_frame<PROBE>(P, O, pix, total, (float)frame);
+          end_frame<PROBE>(P, O, (size_t)py * P.width + px, total, (float)(F.first + fi * F.stride));
           ++fi;
           if (fi >= F.count) {
             active = false;
           } else {
-            frame += F.stride;
-            rng = pixel_seed(P, px, py, frame);
+            rng = pixel_seed(P, px, py, F.first + fi * F.stride);
             total = mk3(0.f, 0.f, 0.f);
             s = 0;
           }
@@ -495,11 +503,7 @@ __global__ __launch_bounds__(kTileBlock, (!STRICT && !EXT) ? RT_SCHED_WAVES : 1)
           skip = -1;
         }
       }
-      if (active) {
-        search_begin<DIEL>(S, o, d, skip, Q);
-      } else {
-        if (!PROBE) O.ids[pix] = id0;
-      }
+      if (active) search_begin<DIEL>(S, o, d, skip, Q);
     }
   }
   tally_wave<PROBE>(O, tile, nrays);
