@@ -27,7 +27,7 @@
 #define RT_SCHED_WAVES 6  // waves per SIMD the untextured fast k_mega_sched is compiled for (80 VGPR; 3840x2160, 10k spheres / terrain: 5 waves 5.42 / 14.65 ms, 6: 5.35 / 14.52, 7: 5.37 / 14.89)
 #endif
 #ifndef RT_SCHED_EXT_WAVES
-#define RT_SCHED_EXT_WAVES 1  // the same for the fast k_mega_sched that carries the extensions (1: no cap, 93 VGPR)
+#define RT_SCHED_EXT_WAVES 5  // the same for the fast k_mega_sched that carries the extensions (96 VGPR; 10k glass spheres 4K batch: uncapped (97 VGPR, 4 waves) 149.7 ms, 5 waves 135.1, 6 waves 143.1)
 #endif
 #ifndef RT_REGEN_BATCHED_TEX_WAVES
 #define RT_REGEN_BATCHED_TEX_WAVES 6  // the textured batched loop (80 VGPR; 8K frame pair 30.1 ms, uncapped 32.3, 7 waves 31.3)
@@ -48,7 +48,7 @@ namespace rt {
 // O.rays[1] and O.rays[2].
 template <bool STRICT, bool BVH, bool EXT, bool APPROX, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq F, Outputs O) {
-  constexpr bool DIEL = EXT && !APPROX;  // dielectric spheres need exact sphere distances
+  constexpr bool DIEL = EXT;
   extern __shared__ int stack[];  // BVH: [entry][thread], S.stack_entries entries (sized by the launch)
   uint32_t px, py;
   pixel_of_thread(px, py);
@@ -214,7 +214,7 @@ constexpr int regen_waves(bool strict, bool tex, int form) {
 // traces like any launch but writes the per-tile costs and nothing else.
 template <bool STRICT, bool BVH, bool EXT, bool APPROX, int FORM, bool PROBE = false>
 __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
-  constexpr bool DIEL = EXT && !APPROX;
+  constexpr bool DIEL = EXT;
   extern __shared__ int stack[];  // BVH: [entry][thread], S.stack_entries entries (sized by the launch)
   // The plain loop is used where one wave's chain of segments sets the launch time: its
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
@@ -419,7 +419,7 @@ template <bool STRICT, bool EXT, bool APPROX, bool PROBE = false>
 __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES : RT_SCHED_WAVES)) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   // [entry][thread], S.stack_entries entries: the launch sizes it by the height of the tree
   // (a 16-level tree leaves room for twice the waves a fixed 32-entry stack would)
-  constexpr bool DIEL = EXT && !APPROX;
+  constexpr bool DIEL = EXT;
   extern __shared__ int stack[];
   const uint32_t tile = ordered_tile(O, tile_rank<kTileBlock>());
   uint32_t px, py;
@@ -594,9 +594,8 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
 
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
                              const FrameSeq &F, const Outputs &O, hipStream_t stream) {
-  // fast policy without a mesh or dielectric spheres: approximate sphere distances behind
-  // exact decisions
-  const bool approx = !strict && S.n_tris == 0u && !S.ior;
+  // fast policy without a mesh: approximate sphere distances behind exact decisions
+  const bool approx = !strict && S.n_tris == 0u;
   const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | ((S.tex || S.ior) ? 1 : 0);
   switch (variant) {
     case 0: return launch_mega_t<false, false, false, false>(nested, P, S, F, O, stream);

@@ -183,7 +183,9 @@ constexpr int kNoHit = 0x7fffffff;  // "no primitive yet": loses every index tie
 //   anything else              decided by the exact arithmetic, tie rule included, on this
 //                              candidate and on the current best (kept as bh, disc).
 // By induction the winner is the exact winner, so hit ids do not depend on the policy;
-// only the distance is approximate (n' * rcp(a), about 2 ulp).
+// only the distance is approximate (n' * rcp(a), about 2 ulp).  The far root of the dielectric
+// sphere a ray travels inside (numerator -bh + s') goes through the same bands, with
+// E = 2^-21 (s' + |bh|), and the best remembers which root it is for the exact re-evaluation.
 template <bool APPROX>
 struct Closest;
 
@@ -220,6 +222,7 @@ template <>
 struct Closest<true> {
   float n, err;    // approximate numerator of the best so far and its error bound
   float bh, disc;  // its inputs, for an exact re-evaluation
+  float sgn;       // which root the best is: -1 near (the shader's), +1 far (inside a dielectric sphere)
   float rcp_a;
   int idx;
   float cx, cy, cz;  // its centre (see Hit)
@@ -229,34 +232,36 @@ struct Closest<true> {
     err = 0.0f;
     bh = 0.0f;
     disc = 0.0f;
+    sgn = -1.0f;
     rcp_a = __builtin_amdgcn_rcpf(a);
     idx = kNoHit;
   }
+  // FAR: the far root, numerator -bh + sqrt(disc) (no early rejection on the sign of bh).
   // LIKELY: the caller expects most tests to find the sphere in front of the ray (code
   // layout only)
-  template <bool LIKELY = false>
+  template <bool LIKELY = false, bool FAR = false>
   __device__ __forceinline__ void sphere(float4 g, int i, f3 o, f3 d, float a) {
     f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
     const float cbh = dot(oc, d);
     const float c = dot(oc, oc) - g.w;
     const float cdisc = __builtin_fmaf(cbh, cbh, -(a * c));
-    if (__builtin_expect(cdisc >= 0.0f && cbh <= 0.0f, LIKELY)) {
+    if (__builtin_expect(cdisc >= 0.0f && (FAR || cbh <= 0.0f), LIKELY)) {
       const float s = __builtin_amdgcn_sqrtf(cdisc);
-      const float cn = -cbh - s;
+      const float cn = FAR ? -cbh + s : -cbh - s;
       // E plus a floor that keeps denormal-small numerators out of the shortcuts
-      const float cerr = __builtin_fmaf(4.76837158e-7f, s - cbh, 1e-20f);
+      const float cerr = __builtin_fmaf(4.76837158e-7f, FAR ? s + __builtin_fabsf(cbh) : s - cbh, 1e-20f);
       const float band = cerr + err;
       if (cn < -cerr || cn > n + band) return;
       bool accept = cn > cerr && cn < n - band;
       if (__builtin_expect(!accept, 0)) {
         // too close to call: the exact rule (rare: the compiler keeps it off the straight path)
-        const float ne = -cbh - ieee_sqrt(cdisc);
+        const float ne = FAR ? -cbh + ieee_sqrt(cdisc) : -cbh - ieee_sqrt(cdisc);
         if (ne > -1e-30f) {
           const float qe = ieee_div(ne, a);
           if (qe >= 0.0f) {
             accept = true;
             if (idx != kNoHit) {
-              const float qb = ieee_div(-bh - ieee_sqrt(disc), a);
+              const float qb = ieee_div(-bh + sgn * ieee_sqrt(disc), a);
               accept = qe < qb || (qe == qb && i < idx);
             }
           }
@@ -267,6 +272,7 @@ struct Closest<true> {
         err = cerr;
         bh = cbh;
         disc = cdisc;
+        sgn = FAR ? 1.0f : -1.0f;
         idx = i;
         cx = g.x;
         cy = g.y;
@@ -274,9 +280,11 @@ struct Closest<true> {
       }
     }
   }
-  // APPROX kernels are launched only for scenes without a mesh and without dielectric spheres
+  __device__ __forceinline__ void sphere_far(float4 g, int i, f3 o, f3 d, float a) {
+    sphere<false, true>(g, i, o, d, a);
+  }
+  // APPROX kernels are launched only for scenes without a mesh
   __device__ __forceinline__ void triangle(const float4 *, int, f3, f3) {}
-  __device__ __forceinline__ void sphere_far(float4, int, f3, f3, float) {}
   __device__ __forceinline__ float dst() const { return idx != kNoHit ? n * rcp_a : 3.402823466e+38f; }
   __device__ __forceinline__ bool any() const { return idx != kNoHit; }
   __device__ __forceinline__ Hit result() const {

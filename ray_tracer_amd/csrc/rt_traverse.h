@@ -237,8 +237,8 @@ constexpr int bvh_stack_words() {
 // next segment must treat specially (see closest_hit_brute's skip).  EXT kernels (launched only
 // while a texture is bound or the scene has dielectric spheres) carry the two extensions: the
 // material colour replaced by a texture sample -- its coordinates are taken at the hit and the
-// texels are fetched last, when little else is live -- and, in kernels that take exact sphere
-// distances (!APPROX), dielectric spheres.  Kernels without EXT carry none of it.
+// texels are fetched last, when little else is live -- and dielectric spheres.  Kernels without
+// EXT carry none of it.
 // from: the skip value the segment that found this hit was traced with.
 // NO_MESH and CENTRE as in hit_surface.
 template <bool STRICT, bool EXT, bool APPROX = false, bool CENTRE = false>
@@ -247,7 +247,7 @@ __device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, int from,
   f3 p, n;
   float4 mc, me, ms;
   const int skip = hit_surface<STRICT, APPROX, CENTRE>(S, h, o, d, p, n, mc, me, ms);
-  if constexpr (EXT && !APPROX) {
+  if constexpr (EXT) {
     if (S.ior && (uint32_t)h.idx < S.n_spheres) {
       const float ior = scene_f32(S.ior, (uint32_t)h.idx);
       if (ior > 0.0f) {

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels)
 template <bool STRICT, bool BVH, bool EXT, bool APPROX>
 __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, uint32_t frame,
                                                   Outputs O) {
-  constexpr bool DIEL = EXT && !APPROX;
+  constexpr bool DIEL = EXT;
   __shared__ int stack[bvh_stack_words<BVH>()];
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
 template <bool STRICT, bool EXT, bool APPROX>
 __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params P, Scene S, WfView V, uint32_t frame,
                                                        Outputs O) {
-  constexpr bool DIEL = EXT && !APPROX;
+  constexpr bool DIEL = EXT;
   extern __shared__ int stack[];  // [entry][thread], S.stack_entries entries (sized by the launch)
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
@@ -623,10 +623,10 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
       break;
     }
     if constexpr (BVH)
-      hipLaunchKernelGGL((k_wf_extend_tree<APPROX, EXT && !APPROX>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
+      hipLaunchKernelGGL((k_wf_extend_tree<APPROX, EXT>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
                          O.ids);
     else
-      hipLaunchKernelGGL((k_wf_extend<BVH, APPROX, EXT && !APPROX>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+      hipLaunchKernelGGL((k_wf_extend<BVH, APPROX, EXT>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                          O.ids);
     hipLaunchKernelGGL((k_wf_shade<STRICT, EXT, E>), dim3(window_blocks), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
@@ -665,7 +665,7 @@ int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &
   *launches = 0;
   for (uint32_t fi = 0; fi < F.count; ++fi) {
     const uint32_t frame = F.first + fi * F.stride;
-    const bool approx = !strict && S.n_tris == 0u && !S.ior;  // see launch_megakernel
+    const bool approx = !strict && S.n_tris == 0u;  // see launch_megakernel
     const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | ((S.tex || S.ior) ? 1 : 0);
 #define RT_WF_CASE(n, a, b, c, e)                                                             \
   case n:                                                                                     \
