@@ -46,9 +46,9 @@ namespace rt {
 
 // COUNT (only with BVH): also tallies LBVH nodes fetched and spheres tested into
 // O.rays[1] and O.rays[2].
-template <bool STRICT, bool BVH, bool EXT, bool APPROX, bool COUNT = false>
+template <bool STRICT, bool BVH, int EXT, bool APPROX, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq F, Outputs O) {
-  constexpr bool DIEL = EXT;
+  constexpr bool DIEL = EXT == kExtDielectric;
   extern __shared__ int stack[];  // BVH: [entry][thread], S.stack_entries entries (sized by the launch)
   uint32_t px, py;
   pixel_of_thread(px, py);
@@ -212,9 +212,9 @@ constexpr int regen_waves(bool strict, bool tex, int form) {
 }
 // PROBE: a cost probe (its own instantiation, so that profiles list it apart from the frames):
 // traces like any launch but writes the per-tile costs and nothing else.
-template <bool STRICT, bool BVH, bool EXT, bool APPROX, int FORM, bool PROBE = false>
-__global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
-  constexpr bool DIEL = EXT;
+template <bool STRICT, bool BVH, int EXT, bool APPROX, int FORM, bool PROBE = false>
+__global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != kExtNone, FORM)) void k_mega_regen(Params P, Scene S, FrameSeq F, Outputs O) {
+  constexpr bool DIEL = EXT == kExtDielectric;
   extern __shared__ int stack[];  // BVH: [entry][thread], S.stack_entries entries (sized by the launch)
   // The plain loop is used where one wave's chain of segments sets the launch time: its
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
@@ -415,11 +415,11 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT, FO
 #define RT_SCHED_TALLY(step, n)
 #endif
 
-template <bool STRICT, bool EXT, bool APPROX, bool PROBE = false>
+template <bool STRICT, int EXT, bool APPROX, bool PROBE = false>
 __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES : RT_SCHED_WAVES)) void k_mega_sched(Params P, Scene S, FrameSeq F, Outputs O) {
   // [entry][thread], S.stack_entries entries: the launch sizes it by the height of the tree
   // (a 16-level tree leaves room for twice the waves a fixed 32-entry stack would)
-  constexpr bool DIEL = EXT;
+  constexpr bool DIEL = EXT == kExtDielectric;
   extern __shared__ int stack[];
   const uint32_t tile = ordered_tile(O, tile_rank<kTileBlock>());
   uint32_t px, py;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
   tally_wave<PROBE>(O, tile, nrays);
 }
 
-template <bool STRICT, bool BVH, bool EXT, bool APPROX>
+template <bool STRICT, bool BVH, int EXT, bool APPROX>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
                                 const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
@@ -585,32 +585,35 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
                                       const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
   const size_t block_stack = (size_t)S.stack_entries * 256u * sizeof(int);
-  if (S.tex || S.ior)
-    hipLaunchKernelGGL((k_mega_nested<false, true, true, false, true>), grid, dim3(256), block_stack, stream, P, S, F, O);
+  if (S.ior)
+    hipLaunchKernelGGL((k_mega_nested<false, true, kExtDielectric, false, true>), grid, dim3(256), block_stack, stream, P, S, F, O);
+  else if (S.tex)
+    hipLaunchKernelGGL((k_mega_nested<false, true, kExtTexture, false, true>), grid, dim3(256), block_stack, stream, P, S, F, O);
   else
-    hipLaunchKernelGGL((k_mega_nested<false, true, false, false, true>), grid, dim3(256), block_stack, stream, P, S, F, O);
+    hipLaunchKernelGGL((k_mega_nested<false, true, kExtNone, false, true>), grid, dim3(256), block_stack, stream, P, S, F, O);
   return hipGetLastError();
+}
+
+template <bool STRICT, bool BVH, bool APPROX>
+static hipError_t launch_mega_e(bool nested, const Params &P, const Scene &S, const FrameSeq &F, const Outputs &O,
+                                hipStream_t stream) {
+  if (S.ior) return launch_mega_t<STRICT, BVH, kExtDielectric, APPROX>(nested, P, S, F, O, stream);
+  if (S.tex) return launch_mega_t<STRICT, BVH, kExtTexture, APPROX>(nested, P, S, F, O, stream);
+  return launch_mega_t<STRICT, BVH, kExtNone, APPROX>(nested, P, S, F, O, stream);
 }
 
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
                              const FrameSeq &F, const Outputs &O, hipStream_t stream) {
   // fast policy without a mesh: approximate sphere distances behind exact decisions
   const bool approx = !strict && S.n_tris == 0u;
-  const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | ((S.tex || S.ior) ? 1 : 0);
-  switch (variant) {
-    case 0: return launch_mega_t<false, false, false, false>(nested, P, S, F, O, stream);
-    case 1: return launch_mega_t<false, false, true, false>(nested, P, S, F, O, stream);
-    case 2: return launch_mega_t<false, true, false, false>(nested, P, S, F, O, stream);
-    case 3: return launch_mega_t<false, true, true, false>(nested, P, S, F, O, stream);
-    case 4: return launch_mega_t<true, false, false, false>(nested, P, S, F, O, stream);
-    case 5: return launch_mega_t<true, false, true, false>(nested, P, S, F, O, stream);
-    case 6: return launch_mega_t<true, true, false, false>(nested, P, S, F, O, stream);
-    case 7: return launch_mega_t<true, true, true, false>(nested, P, S, F, O, stream);
-    case 8: return launch_mega_t<false, false, false, true>(nested, P, S, F, O, stream);
-    case 9: return launch_mega_t<false, false, true, true>(nested, P, S, F, O, stream);
-    case 10: return launch_mega_t<false, true, false, true>(nested, P, S, F, O, stream);
-    default: return launch_mega_t<false, true, true, true>(nested, P, S, F, O, stream);
-  }
+  if (strict)
+    return bvh ? launch_mega_e<true, true, false>(nested, P, S, F, O, stream)
+               : launch_mega_e<true, false, false>(nested, P, S, F, O, stream);
+  if (approx)
+    return bvh ? launch_mega_e<false, true, true>(nested, P, S, F, O, stream)
+               : launch_mega_e<false, false, true>(nested, P, S, F, O, stream);
+  return bvh ? launch_mega_e<false, true, false>(nested, P, S, F, O, stream)
+             : launch_mega_e<false, false, false>(nested, P, S, F, O, stream);
 }
 
 }  // namespace rt

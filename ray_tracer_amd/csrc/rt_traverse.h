@@ -234,20 +234,22 @@ constexpr int bvh_stack_words() {
 }
 
 // One hit bounce: surface at the hit, then the shader's scatter.  Returns the primitive the
-// next segment must treat specially (see closest_hit_brute's skip).  EXT kernels (launched only
-// while a texture is bound or the scene has dielectric spheres) carry the two extensions: the
-// material colour replaced by a texture sample -- its coordinates are taken at the hit and the
-// texels are fetched last, when little else is live -- and dielectric spheres.  Kernels without
-// EXT carry none of it.
+// next segment must treat specially (see closest_hit_brute's skip).  EXT: which extensions the
+// kernel carries.  kExtTexture (launched while a texture is bound): the material colour
+// replaced by a texture sample -- its coordinates are taken at the hit and the texels are
+// fetched last, when little else is live.  kExtDielectric (launched while the scene has
+// dielectric spheres): those, and the texture if one is bound as well.  kExtNone: neither
+// (the 8K textured frame runs 5 % slower through a kernel that also carries the dielectric code).
 // from: the skip value the segment that found this hit was traced with.
 // NO_MESH and CENTRE as in hit_surface.
-template <bool STRICT, bool EXT, bool APPROX = false, bool CENTRE = false>
+constexpr int kExtNone = 0, kExtTexture = 1, kExtDielectric = 2;
+template <bool STRICT, int EXT, bool APPROX = false, bool CENTRE = false>
 __device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, int from, uint32_t &rng, f3 &o,
                                          f3 &d, f3 &light, f3 &colour) {
   f3 p, n;
   float4 mc, me, ms;
   const int skip = hit_surface<STRICT, APPROX, CENTRE>(S, h, o, d, p, n, mc, me, ms);
-  if constexpr (EXT) {
+  if constexpr (EXT == kExtDielectric) {
     if (S.ior && (uint32_t)h.idx < S.n_spheres) {
       const float ior = scene_f32(S.ior, (uint32_t)h.idx);
       if (ior > 0.0f) {
@@ -263,7 +265,7 @@ __device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, int from,
   }
   bool textured = false;
   float tu = 0.0f, tv = 0.0f;
-  if constexpr (EXT) {
+  if constexpr (EXT != kExtNone) {
     textured = S.tex && (uint32_t)h.idx - S.tex->first_prim < S.tex->n_prims;
     if (textured) {
       texture_coords(*S.tex, p, n, tu, tv);
@@ -273,7 +275,7 @@ __device__ __forceinline__ int shade_hit(const Scene &S, const Hit &h, int from,
   }
   const float is_spec = scatter<STRICT>(p, n, mc.w, me, ms.w, rng, o, d, light, colour);
   f3 albedo = mk3(mc.x, mc.y, mc.z);
-  if constexpr (EXT) {
+  if constexpr (EXT != kExtNone) {
     // a specular bounce gives the colour weight 0 and every texel is finite: skip the fetch
     if (textured && is_spec == 0.0f) albedo = texture_sample(*S.tex, tu, tv);
   }

@@ -305,7 +305,7 @@ __device__ __forceinline__ bool path_end(const Params &P, const WfView &V, const
   return true;
 }
 
-template <bool STRICT, bool EXT, int E>
+template <bool STRICT, int EXT, int E>
 __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, uint32_t slot,
                                                   uint32_t frame, Outputs O) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -368,10 +368,10 @@ __global__ __launch_bounds__(256) void k_wf_compact(WfView V, uint32_t n_pixels)
 
 // Finishes every pixel of the drain queue in registers: the loop of the regenerating
 // megakernel, resumed from the stored path state, for this one frame.
-template <bool STRICT, bool BVH, bool EXT, bool APPROX>
+template <bool STRICT, bool BVH, int EXT, bool APPROX>
 __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, uint32_t frame,
                                                   Outputs O) {
-  constexpr bool DIEL = EXT;
+  constexpr bool DIEL = EXT == kExtDielectric;
   __shared__ int stack[bvh_stack_words<BVH>()];
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
@@ -428,10 +428,10 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
 
 // The drain launch for LBVH scenes: the same resumption, in k_mega_sched's wave-scheduled
 // form (inner / leaf / shade steps chosen by waiting-lane count).
-template <bool STRICT, bool EXT, bool APPROX>
+template <bool STRICT, int EXT, bool APPROX>
 __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params P, Scene S, WfView V, uint32_t frame,
                                                        Outputs O) {
-  constexpr bool DIEL = EXT;
+  constexpr bool DIEL = EXT == kExtDielectric;
   extern __shared__ int stack[];  // [entry][thread], S.stack_entries entries (sized by the launch)
   const uint32_t n = V.counts[16];
   const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
@@ -589,7 +589,7 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
   return 0;
 }
 
-template <bool STRICT, bool BVH, bool EXT, bool APPROX>
+template <bool STRICT, bool BVH, int EXT, bool APPROX>
 static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const Params &P,
                     const Scene &S, uint32_t frame, const Outputs &O, hipStream_t stream,
                     uint32_t *launches, std::string *err) {
@@ -623,10 +623,10 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
       break;
     }
     if constexpr (BVH)
-      hipLaunchKernelGGL((k_wf_extend_tree<APPROX, EXT>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
+      hipLaunchKernelGGL((k_wf_extend_tree<APPROX, EXT == kExtDielectric>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
                          O.ids);
     else
-      hipLaunchKernelGGL((k_wf_extend<BVH, APPROX, EXT>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
+      hipLaunchKernelGGL((k_wf_extend<BVH, APPROX, EXT == kExtDielectric>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                          O.ids);
     hipLaunchKernelGGL((k_wf_shade<STRICT, EXT, E>), dim3(window_blocks), dim3(256),
                        0, stream, P, S, V, slot, frame, O);
@@ -666,24 +666,23 @@ int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &
   for (uint32_t fi = 0; fi < F.count; ++fi) {
     const uint32_t frame = F.first + fi * F.stride;
     const bool approx = !strict && S.n_tris == 0u;  // see launch_megakernel
-    const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0) | ((S.tex || S.ior) ? 1 : 0);
-#define RT_WF_CASE(n, a, b, c, e)                                                             \
-  case n:                                                                                     \
-    rc = wf_frame<a, b, c, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err);  \
+    const int ext = S.ior ? kExtDielectric : (S.tex ? kExtTexture : kExtNone);
+    const int variant = (approx ? 8 : 0) | (strict ? 4 : 0) | (bvh ? 2 : 0);
+#define RT_WF_CASE(n, a, b, e)                                                                              \
+  case n:                                                                                                   \
+    rc = ext == kExtDielectric                                                                              \
+             ? wf_frame<a, b, kExtDielectric, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err) \
+         : ext == kExtTexture                                                                               \
+             ? wf_frame<a, b, kExtTexture, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err)  \
+             : wf_frame<a, b, kExtNone, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err);    \
     break;
     switch (variant) {
-      RT_WF_CASE(0, false, false, false, false)
-      RT_WF_CASE(1, false, false, true, false)
-      RT_WF_CASE(2, false, true, false, false)
-      RT_WF_CASE(3, false, true, true, false)
-      RT_WF_CASE(4, true, false, false, false)
-      RT_WF_CASE(5, true, false, true, false)
-      RT_WF_CASE(6, true, true, false, false)
-      RT_WF_CASE(7, true, true, true, false)
-      RT_WF_CASE(8, false, false, false, true)
-      RT_WF_CASE(9, false, false, true, true)
-      RT_WF_CASE(10, false, true, false, true)
-      RT_WF_CASE(11, false, true, true, true)
+      RT_WF_CASE(0, false, false, false)
+      RT_WF_CASE(2, false, true, false)
+      RT_WF_CASE(4, true, false, false)
+      RT_WF_CASE(6, true, true, false)
+      RT_WF_CASE(8, false, false, true)
+      RT_WF_CASE(10, false, true, true)
     }
 #undef RT_WF_CASE
     if (rc) return rc;
