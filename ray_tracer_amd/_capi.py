@@ -118,9 +118,20 @@ lib.rt_destroy.argtypes = [C.c_void_p]
 lib.rt_set_params.argtypes = [C.c_void_p, C.c_void_p]
 lib.rt_set_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 lib.rt_set_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
-lib.rt_set_mesh_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
 lib.rt_set_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-lib.rt_set_dielectric.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+
+
+def _optional(name: str, argtypes) -> None:
+    """Entry points a library selected with RT_HIP_LIB may predate (A/B runs against older
+    builds): calling one that is missing raises AttributeError at the call, not at import."""
+    try:
+        getattr(lib, name).argtypes = argtypes
+    except AttributeError:
+        pass
+
+
+_optional("rt_set_mesh_device", [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p])
+_optional("rt_set_dielectric", [C.c_void_p, C.c_void_p, C.c_uint32])
 lib.rt_brick_texture.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
 lib.rt_brick_texture.restype = None
 lib.rt_ingest_error.restype = C.c_char_p
@@ -372,7 +383,7 @@ class _StaticJob(C.Structure):
                 ("d_ids", C.c_void_p), ("d_rays", C.c_void_p)]
 
 
-lib.rt_render_static.argtypes = [C.POINTER(_StaticJob)]
+_optional("rt_render_static", [C.POINTER(_StaticJob)])
 
 
 def render_static(width: int, height: int, ubo: np.ndarray, d_spheres64: int, n_spheres: int,

@@ -135,12 +135,18 @@ __device__ __forceinline__ uint32_t tile_thread() {
 
 // per-wave epilogue: path segments into the ray counter, slowest pixel into the tile's cost
 // (a probe launch records costs and nothing else)
+// "This launch is a cost probe."  Probe launches are their own instantiations (PROBE), in which
+// the test folds away; the frame kernels keep the run-time flag of the launch in the test, which
+// is never set for them: with the test folded away there too, the 1920x1080 frame of the default
+// scene came out 3 % slower (1.245 against 1.209 ms; the chain of the slowest wave is that
+// sensitive to how the compiler lays out the loop).
+#define RT_IS_PROBE (PROBE || O.probe)
 template <bool PROBE>
 __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint32_t nrays) {
   const uint32_t wsum = wave_sum_u32(nrays);
   const uint32_t wmax = wave_max_u32(nrays);
   if ((threadIdx.x & 63u) == 0) {
-    if (wsum && !PROBE) atomicAdd(O.rays, (unsigned long long)wsum);
+    if (wsum && !RT_IS_PROBE) atomicAdd(O.rays, (unsigned long long)wsum);
     if (O.tile_cost) atomicMax(O.tile_cost + tile, wmax);
   }
 }
@@ -151,7 +157,7 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
 template <bool PROBE>
 __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, size_t pix, f3 total,
                                           float frame_f) {
-  if (PROBE) return;
+  if (RT_IS_PROBE) return;
   float4 acc = O.accum[pix];
   uchar4 img = O.rgba8[pix];
   frame_epilogue(P, total, frame_f, O.linear_accum, acc, img);
@@ -163,14 +169,20 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
 // the environment for a path that escaped, sample sum, frame epilogue, next primary ray.
 // (A macro over the kernel's locals rather than a lambda: with a lambda the batched kernel,
 // which is compiled against a register cap, came out 4 % slower.)
-// The batched loops and k_mega_sched store a pixel's primary-hit id where it is found (first
-// segment of sample 0 of each frame, the last frame's store stays) instead of carrying it to
-// the end of the launch in a register.  The timeline build keeps its records in that array.
+// The batched launch and k_mega_sched (kIdsEarly) store a pixel's primary-hit id where it is
+// found (first segment of sample 0 of each frame, the last frame's store stays) instead of
+// carrying it to the end of the launch in a register: that register was one of three the
+// batched kernel spilled at its 72-VGPR cap.  The plain and mixed launches, whose time is one
+// wave's chain, keep the register and store once at the end (2 % faster there).  The timeline
+// build keeps its records in that array.
 #ifdef RT_MEASURE_TIMELINE
 #define RT_STORE_FIRST_ID(idx)
 #else
 #define RT_STORE_FIRST_ID(idx) \
-        if (!PROBE && s == 0 && b == 0) O.ids[(size_t)py * P.width + px] = (idx)
+        if (s == 0 && b == 0) { \
+          if (kIdsEarly) { if (!RT_IS_PROBE) O.ids[(size_t)py * P.width + px] = (idx); } \
+          else id0 = (idx); \
+        }
 #endif
 
 #define RT_END_PATHS() \
@@ -237,6 +249,8 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
 #endif
   if (px < P.width && py < P.height && F.count) {
     const f3 base = pixel_direction(P, px, py);
+    constexpr bool kIdsEarly = FORM == kRegenBatched;
+    int id0 = -1;
 
     uint32_t fi = 0;
     uint32_t rng = pixel_seed(P, px, py, F.first);
@@ -320,7 +334,6 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
       // (this loop keeps the pixel's accumulation value and 8-bit colour in registers: with
       // the read-modify-write of end_frame inside it the chain of a lone wave is 12 % longer)
       const size_t pix = (size_t)py * P.width + px;
-      int id0 = -1;
       uint32_t frame = F.first;
       float4 acc = O.accum[pix];
       uchar4 img = O.rgba8[pix];
@@ -362,14 +375,14 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
           }
         }
       }
-      if (!PROBE) {
+      if (!RT_IS_PROBE) {
         O.accum[pix] = acc;
         O.rgba8[pix] = img;
-#ifndef RT_MEASURE_TIMELINE
-        O.ids[pix] = id0;
-#endif
       }
     }
+#ifndef RT_MEASURE_TIMELINE
+    if (!kIdsEarly && !RT_IS_PROBE) O.ids[(size_t)py * P.width + px] = id0;
+#endif
   }
   tally_wave<PROBE>(O, tile, nrays);
 #ifdef RT_MEASURE_TIMELINE
@@ -427,6 +440,9 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
   uint32_t nrays = 0;
   bool active = px < P.width && py < P.height && F.count;
   const f3 base = pixel_direction(P, px, py);
+  constexpr bool kIdsEarly = true;
+  int id0 = -1;  // (unused here: RT_STORE_FIRST_ID stores at once)
+  (void)id0;
   uint32_t fi = 0;
   uint32_t rng = pixel_seed(P, px, py, F.first);
   f3 total = mk3(0.f, 0.f, 0.f);

@@ -9,6 +9,7 @@ with rt.Renderer(w, h) as r:
     r.set_params(ubo); r.set_spheres(rt.default_scene())
     r.render(0, 1, 1); r.stats()
     t = []
-    for f in range(1, 10):
+    for f in range(1, 41):
         r.render(f, 1, 1); t.append(r.stats().last_render_ms)
-    print(os.environ.get("RT_HIP_LIB", "current").split("/")[-2:][0], f"min {min(t):.3f} med {sorted(t)[len(t)//2]:.3f}", " ".join(f"{x:.2f}" for x in t), flush=True)
+    late = sorted(t[16:])   # the tile order has settled by then (refreshed after launches 1, 2, 4, 8, 16)
+    print(os.environ.get("RT_HIP_LIB", "current").split("/")[-2:][0], f"min {min(t):.3f} med(17..40) {late[len(late)//2]:.3f} mean(17..40) {sum(late)/len(late):.3f}", flush=True)
