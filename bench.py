@@ -300,12 +300,7 @@ def main() -> None:
         st = [rr.stats() for rr in renderers]
         return sum(s.rays for s in st), sum(s.total_render_ms for s in st)
 
-    # cold first frame of a context (cost probe + unordered tiles), reported beside the steady state
     cold_ms = None
-    if world == 1 and not args.no_side_runs:
-        step(0)
-        fence()
-        cold_ms = renderers[0].stats().last_render_ms
     for i in range(args.warmup):
         step(i)
     fence()
@@ -337,6 +332,12 @@ def main() -> None:
                     x.render(f * wl["frames"], wl["frames"], 1)
                     t.append(x.stats().last_render_ms)
                 return sorted(t)[len(t) // 2], x.stats()
+        # first launch of a NEW context on a process whose kernels are loaded: no tile costs yet, so
+        # a two-sample cost probe and the ordering pass precede the frame (all inside the figure)
+        with rt.Renderer(WIDTH, HEIGHT, mode=mode, flags=0, device=local_rank) as x:
+            apply_scene(x, rt, scene)
+            x.render(0, wl["frames"], 1)
+            cold_ms = x.stats().last_render_ms
         if args.config in (0, 1, 2, 3):
             other_ms, _ = side(rt.MODE_WAVEFRONT, 0, 3 if args.config != 2 else 1)
         strict_ms, _ = side(rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH, 3 if not heavy else 1)
