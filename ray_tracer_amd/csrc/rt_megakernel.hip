@@ -220,6 +220,12 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
 // tiles with the longest chains, which set the launch time) and the batched loop for the rest
 // (whose job is throughput).
 constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
+#ifndef RT_SPARSE_RANKS
+#define RT_SPARSE_RANKS 3
+#endif
+#ifndef RT_SPARSE_FEW_TILES
+#define RT_SPARSE_FEW_TILES 4096  // 1280x720 has 3,600 tiles, 1920x1080 8,160
+#endif
 // waves per SIMD a form is compiled for (the register budget follows from it)
 constexpr int regen_waves(bool strict, bool tex, int form) {
   if (form != kRegenBatched || strict) return RT_MEGA_WAVES;
@@ -241,7 +247,30 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
   constexpr int SHADE_BATCH = FORM == kRegenBatched ? RT_REGEN_SHADE_BATCH : 1;
   constexpr int END_BATCH = FORM == kRegenBatched ? RT_REGEN_END_BATCH : 8;
   constexpr int BLOCK = BVH ? 256 : kTileBlock;
-  const uint32_t rank = tile_rank<BLOCK>(), tile_t = tile_thread<BLOCK>();
+  // Mixed form: the tiles of the first O.sparse_ranks ranks, whose chains bound the launch, are
+  // spread over 2^O.sparse_shift times the waves, each with that fraction of its lanes switched
+  // on (whole rows of the wave's 8x8 pixels).  What stretches the chain of the slowest lane is
+  // the path-end code that runs, in nearly every iteration, for whichever OTHER lanes of its wave
+  // need it; with a quarter of the lanes it runs a quarter as often.  The extra waves cost
+  // issue slots for the whole launch, so only a few tiles pay: 1920x1080 1.207 -> 1.160 ms with
+  // 3 tiles of 4 x 16 lanes; 16 tiles 1.187, 64 tiles 1.264; 8 x 8 lanes 1.17 at best.  1280x720,
+  // where the device is never full: 1.25 -> 1.09 ms with 8 x 8 lanes, 3 to 64 tiles alike.
+  uint32_t rank = tile_rank<BLOCK>(), tile_t = tile_thread<BLOCK>();
+  bool lane_on = true;
+  if constexpr (FORM == kRegenMixed) {
+    const uint32_t k = O.sparse_shift;  // 1, 2 or 3: each wave becomes 2, 4 or 8
+    const uint32_t nb = (O.sparse_ranks * 4u) << k;
+    if (blockIdx.x < nb) {
+      rank = blockIdx.x >> (2u + k);
+      const uint32_t sub = blockIdx.x & ((4u << k) - 1u);
+      tile_t = ((sub >> k) << 6) | threadIdx.x;
+      lane_on = (threadIdx.x >> (6u - k)) == (sub & ((1u << k) - 1u));
+    } else {
+      const uint32_t bb = blockIdx.x - O.sparse_ranks * 4u * ((1u << k) - 1u);
+      rank = bb >> 2;
+      tile_t = ((bb & 3u) << 6) | threadIdx.x;
+    }
+  }
   const bool batched = FORM == kRegenMixed ? rank >= O.chain_ranks : FORM == kRegenBatched;
   const uint32_t tile = ordered_tile(O, rank);
   uint32_t px, py;
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
 #ifdef RT_MEASURE_TIMELINE
   const unsigned long long t_begin = wall_clock64();
 #endif
-  if (px < P.width && py < P.height && F.count) {
+  if (px < P.width && py < P.height && F.count && lane_on) {
     const f3 base = pixel_direction(P, px, py);
     constexpr bool kIdsEarly = FORM == kRegenBatched;
     int id0 = -1;
@@ -607,8 +636,28 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain, true>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else if (O.probe)
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain, true>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
-    else if (form == kRegenMixed)
-      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenMixed : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
+    else if (form == kRegenMixed) {
+      dim3 mixed_tiles = wave_tiles;
+      // few tiles (the device is not full for most of the launch): 16 tiles in waves of 8 lanes;
+      // more: 3 tiles in waves of 16 lanes.  RT_SPARSE_RANKS / RT_SPARSE_SHIFT override (measurements).
+      static const int sparse_env = [] {
+        const char *e = getenv("RT_SPARSE_RANKS");
+        return e ? (int)strtoul(e, nullptr, 10) : -1;
+      }();
+      static const int shift_env = [] {
+        const char *e = getenv("RT_SPARSE_SHIFT");
+        const int v = e ? (int)strtoul(e, nullptr, 10) : -1;
+        return v < 0 ? -1 : v < 1 ? 1 : v > 3 ? 3 : v;
+      }();
+      const bool few = O.n_tiles <= RT_SPARSE_FEW_TILES;
+      const uint32_t sparse = sparse_env >= 0 ? (uint32_t)sparse_env : few ? 16u : (uint32_t)RT_SPARSE_RANKS;
+      const uint32_t shift = shift_env >= 0 ? (uint32_t)shift_env : few ? 3u : 2u;
+      Q.sparse_ranks = sparse < Q.chain_ranks ? sparse : Q.chain_ranks;
+      if (Q.sparse_ranks > tiles.x) Q.sparse_ranks = tiles.x;
+      Q.sparse_shift = shift;
+      mixed_tiles.x += Q.sparse_ranks * 4u * ((1u << shift) - 1u);
+      hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenMixed : kRegenPlain>), mixed_tiles, wave_block, 0, stream, P, S, F, Q);
+    }
     else if (form == kRegenBatched)
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else
