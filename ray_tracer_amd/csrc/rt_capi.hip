@@ -71,6 +71,10 @@ int guarded(const char *who, F body) {
 struct rt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // the context's own second stream: a launch that is two kernels side by side forks to it from
+  // `stream` and joins back, so callers see one stream as before
+  rt::SideStream side{nullptr, nullptr, nullptr};
+  bool have_side = false;
   uint32_t width = 0, height = 0, mode = 0, flags = 0;
   size_t n_pixels = 0;
 
@@ -278,6 +282,13 @@ static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
     return bail(e, "hipMalloc(tile order)");
   if ((e = hipMemsetAsync(c->d_tile_cost, 0, c->n_tiles * sizeof(uint32_t), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(tile cost)");
+  if ((e = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail(e, "hipStreamCreate(side stream)");
+  if ((e = hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming)) != hipSuccess)
+    return bail(e, "hipEventCreate(fork)");
+  if ((e = hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming)) != hipSuccess)
+    return bail(e, "hipEventCreate(join)");
+  c->have_side = true;
   if (const char *env = std::getenv("RT_TILE_ORDER")) c->use_tile_order = env[0] != '0';
   if (const char *env = std::getenv("RT_TILE_PROBE")) c->use_probe = env[0] != '0';
   int rc = rt_clear(c);
@@ -293,6 +304,12 @@ int rt_destroy(rt_ctx *c) {
   if (!c) return RT_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->side.stream) {
+    hipStreamSynchronize(c->side.stream);
+    hipStreamDestroy(c->side.stream);
+  }
+  if (c->side.fork) hipEventDestroy(c->side.fork);
+  if (c->side.join) hipEventDestroy(c->side.join);
   if (c->own_accum && c->d_accum) hipFree(c->d_accum);
   if (c->d_rgba8) hipFree(c->d_rgba8);
   if (c->d_ids) hipFree(c->d_ids);
@@ -686,7 +703,8 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
       launches = 1;
     } else {
       const bool nested = degenerate || c->mode == RT_MODE_MEGAKERNEL_NESTED;
-      he = rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream);
+      he = rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream,
+                                 c->have_side ? &c->side : nullptr);
       launches = 1;
       ordered = !nested && c->use_tile_order;
     }

@@ -7,9 +7,17 @@
 
 namespace rt {
 
-// rt_megakernel.hip
+// A second stream (and the two events that fork from and join the caller's stream) for launches
+// that run two kernels side by side.
+struct SideStream {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
+
+// rt_megakernel.hip.  side may be null: every launch is then a single kernel on `stream`.
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
-                             const FrameSeq &F, const Outputs &O, hipStream_t stream);
+                             const FrameSeq &F, const Outputs &O, hipStream_t stream,
+                             const SideStream *side = nullptr);
 
 // fast math, LBVH, nested loops, plus node/sphere tallies in O.rays[1], O.rays[2]
 hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const FrameSeq &F,

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
   // where the device is never full: 1.25 -> 1.09 ms with 8 x 8 lanes, 3 to 64 tiles alike.
   uint32_t rank = tile_rank<BLOCK>(), tile_t = tile_thread<BLOCK>();
   bool lane_on = true;
-  if constexpr (FORM == kRegenMixed) {
+  if constexpr (FORM == kRegenMixed || (FORM == kRegenPlain && !BVH && !PROBE)) {
     const uint32_t k = O.sparse_shift;  // 1, 2 or 3: each wave becomes 2, 4 or 8
     const uint32_t nb = (O.sparse_ranks * 4u) << k;
     if (blockIdx.x < nb) {
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
       tile_t = ((bb & 3u) << 6) | threadIdx.x;
     }
   }
+  rank += O.rank_base;  // (a launch may cover the tail of the order only)
   const bool batched = FORM == kRegenMixed ? rank >= O.chain_ranks : FORM == kRegenBatched;
   const uint32_t tile = ordered_tile(O, rank);
   uint32_t px, py;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
 
 template <bool STRICT, bool BVH, int EXT, bool APPROX>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
-                                const Outputs &O, hipStream_t stream) {
+                                const Outputs &O, hipStream_t stream, const SideStream *side) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
   dim3 tiles(O.n_tiles, 1, 1);  // k_mega_regen and k_mega_sched take tiles from a 1-D grid
 #ifdef RT_DEBUG_TILE_LIMIT
@@ -637,9 +638,14 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     else if (O.probe)
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain, true>), wave_tiles, wave_block, 0, stream, P, S, F, Q);
     else if (form == kRegenMixed) {
-      dim3 mixed_tiles = wave_tiles;
-      // few tiles (the device is not full for most of the launch): 16 tiles in waves of 8 lanes;
-      // more: 3 tiles in waves of 16 lanes.  RT_SPARSE_RANKS / RT_SPARSE_SHIFT override (measurements).
+      // The tiles of the first chain_ranks ranks run the plain loop, the first sparse_ranks of
+      // them in waves of 64 >> shift lanes (see the kernel); the rest run the batched loop.
+      // With a side stream these are two launches side by side, each kernel with its own
+      // register budget (plain 75 VGPR, batched 72 at 7 waves per SIMD) and the batched one
+      // with its large batches: 1920x1080 1.165 -> 1.11 ms against the one kernel that holds
+      // both loops (87 VGPR, 5 waves per SIMD).  The chain launch goes first, so its waves are
+      // resident from the start.  RT_SPARSE_RANKS / RT_SPARSE_SHIFT / RT_TWO_LAUNCHES=0
+      // override (measurements).
       static const int sparse_env = [] {
         const char *e = getenv("RT_SPARSE_RANKS");
         return e ? (int)strtoul(e, nullptr, 10) : -1;
@@ -649,13 +655,41 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
         const int v = e ? (int)strtoul(e, nullptr, 10) : -1;
         return v < 0 ? -1 : v < 1 ? 1 : v > 3 ? 3 : v;
       }();
+      static const bool two_env = [] {
+        const char *e = getenv("RT_TWO_LAUNCHES");
+        return !(e && e[0] == '0');
+      }();
+      const bool two = B && side && two_env && Q.chain_ranks < tiles.x;
       const bool few = O.n_tiles <= RT_SPARSE_FEW_TILES;
-      const uint32_t sparse = sparse_env >= 0 ? (uint32_t)sparse_env : few ? 16u : (uint32_t)RT_SPARSE_RANKS;
-      const uint32_t shift = shift_env >= 0 ? (uint32_t)shift_env : few ? 3u : 2u;
+      // (measured optima: one launch 3 tiles x 4 waves, two launches 2 tiles x 8; launches that
+      // never fill the device 16 tiles x 8)
+      const uint32_t sparse = sparse_env >= 0 ? (uint32_t)sparse_env : few ? 16u : two ? 2u : (uint32_t)RT_SPARSE_RANKS;
+      const uint32_t shift = shift_env >= 0 ? (uint32_t)shift_env : (few || two) ? 3u : 2u;
       Q.sparse_ranks = sparse < Q.chain_ranks ? sparse : Q.chain_ranks;
       if (Q.sparse_ranks > tiles.x) Q.sparse_ranks = tiles.x;
       Q.sparse_shift = shift;
-      mixed_tiles.x += Q.sparse_ranks * 4u * ((1u << shift) - 1u);
+      const uint32_t extra = Q.sparse_ranks * 4u * ((1u << shift) - 1u);
+      if (two) {
+        hipError_t e = hipEventRecord(side->fork, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+        if (e != hipSuccess) return e;
+        const dim3 chain_grid(Q.chain_ranks * 4u + extra, 1, 1), rest_grid((tiles.x - Q.chain_ranks) * 4u, 1, 1);
+        hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain>), chain_grid, wave_block, 0, side->stream, P, S, F, Q);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
+        Outputs T = Q;
+        T.rank_base = Q.chain_ranks;
+        T.sparse_ranks = 0;
+        if (e == hipSuccess) {
+          hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain>), rest_grid, wave_block, 0, stream, P, S, F, T);
+          e = hipGetLastError();
+        }
+        // the caller's stream continues only when both launches are done (also after a failure
+        // above: whatever reached the side stream is joined)
+        const hipError_t ej = hipStreamWaitEvent(stream, side->join, 0);
+        return e != hipSuccess ? e : ej;
+      }
+      const dim3 mixed_tiles(wave_tiles.x + extra, 1, 1);
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenMixed : kRegenPlain>), mixed_tiles, wave_block, 0, stream, P, S, F, Q);
     }
     else if (form == kRegenBatched)
@@ -681,24 +715,24 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
 
 template <bool STRICT, bool BVH, bool APPROX>
 static hipError_t launch_mega_e(bool nested, const Params &P, const Scene &S, const FrameSeq &F, const Outputs &O,
-                                hipStream_t stream) {
-  if (S.ior) return launch_mega_t<STRICT, BVH, kExtDielectric, APPROX>(nested, P, S, F, O, stream);
-  if (S.tex) return launch_mega_t<STRICT, BVH, kExtTexture, APPROX>(nested, P, S, F, O, stream);
-  return launch_mega_t<STRICT, BVH, kExtNone, APPROX>(nested, P, S, F, O, stream);
+                                hipStream_t stream, const SideStream *side) {
+  if (S.ior) return launch_mega_t<STRICT, BVH, kExtDielectric, APPROX>(nested, P, S, F, O, stream, side);
+  if (S.tex) return launch_mega_t<STRICT, BVH, kExtTexture, APPROX>(nested, P, S, F, O, stream, side);
+  return launch_mega_t<STRICT, BVH, kExtNone, APPROX>(nested, P, S, F, O, stream, side);
 }
 
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
-                             const FrameSeq &F, const Outputs &O, hipStream_t stream) {
+                             const FrameSeq &F, const Outputs &O, hipStream_t stream, const SideStream *side) {
   // fast policy without a mesh: approximate sphere distances behind exact decisions
   const bool approx = !strict && S.n_tris == 0u;
   if (strict)
-    return bvh ? launch_mega_e<true, true, false>(nested, P, S, F, O, stream)
-               : launch_mega_e<true, false, false>(nested, P, S, F, O, stream);
+    return bvh ? launch_mega_e<true, true, false>(nested, P, S, F, O, stream, side)
+               : launch_mega_e<true, false, false>(nested, P, S, F, O, stream, side);
   if (approx)
-    return bvh ? launch_mega_e<false, true, true>(nested, P, S, F, O, stream)
-               : launch_mega_e<false, false, true>(nested, P, S, F, O, stream);
-  return bvh ? launch_mega_e<false, true, false>(nested, P, S, F, O, stream)
-             : launch_mega_e<false, false, false>(nested, P, S, F, O, stream);
+    return bvh ? launch_mega_e<false, true, true>(nested, P, S, F, O, stream, side)
+               : launch_mega_e<false, false, true>(nested, P, S, F, O, stream, side);
+  return bvh ? launch_mega_e<false, true, false>(nested, P, S, F, O, stream, side)
+             : launch_mega_e<false, false, false>(nested, P, S, F, O, stream, side);
 }
 
 }  // namespace rt
