@@ -452,6 +452,11 @@ def main() -> None:
                 "algorithmic_flops_per_launch": flops,
                 "note": "FP32 vector issue bound (no MFMA in a path tracer); HBM traffic is ~50 B/pixel/frame",
             }
+            if args.mode == "megakernel" and args.config == 1:
+                roof["kernels_per_launch"] = ("two k_mega_regen kernels side by side on two streams: the tiles with the "
+                                              "longest chains in the plain loop, the rest in the batched loop; "
+                                              "launch_ms is the HIP-event time around both, and a kernel trace lists "
+                                              "each with about that duration")
         out = {
             "metric": "Mrays/sec (all bounces)",
             "value": total_rays / elapsed / 1e6,

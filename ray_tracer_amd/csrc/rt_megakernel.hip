@@ -219,7 +219,9 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
 // kRegenMixed = the plain loop for the first O.chain_ranks blocks of an ordered launch (the
 // tiles with the longest chains, which set the launch time) and the batched loop for the rest
 // (whose job is throughput).
-constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
+// kRegenChain = the plain loop for a launch that covers only the head of the order (the chain
+// tiles), run beside a batched launch of the rest.
+constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2, kRegenChain = 3;
 #ifndef RT_SPARSE_RANKS
 #define RT_SPARSE_RANKS 3
 #endif
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
   // where the device is never full: 1.25 -> 1.09 ms with 8 x 8 lanes, 3 to 64 tiles alike.
   uint32_t rank = tile_rank<BLOCK>(), tile_t = tile_thread<BLOCK>();
   bool lane_on = true;
-  if constexpr (FORM == kRegenMixed || (FORM == kRegenPlain && !BVH && !PROBE)) {
+  if constexpr (FORM == kRegenMixed || FORM == kRegenChain) {
     const uint32_t k = O.sparse_shift;  // 1, 2 or 3: each wave becomes 2, 4 or 8
     const uint32_t nb = (O.sparse_ranks * 4u) << k;
     if (blockIdx.x < nb) {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
       tile_t = ((bb & 3u) << 6) | threadIdx.x;
     }
   }
-  rank += O.rank_base;  // (a launch may cover the tail of the order only)
+  if constexpr (FORM == kRegenBatched) rank += O.rank_base;  // (a launch may cover the tail of the order only)
   const bool batched = FORM == kRegenMixed ? rank >= O.chain_ranks : FORM == kRegenBatched;
   const uint32_t tile = ordered_tile(O, rank);
   uint32_t px, py;
@@ -640,10 +642,10 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     else if (form == kRegenMixed) {
       // The tiles of the first chain_ranks ranks run the plain loop, the first sparse_ranks of
       // them in waves of 64 >> shift lanes (see the kernel); the rest run the batched loop.
-      // With a side stream these are two launches side by side, each kernel with its own
-      // register budget (plain 75 VGPR, batched 72 at 7 waves per SIMD) and the batched one
-      // with its large batches: 1920x1080 1.165 -> 1.11 ms against the one kernel that holds
-      // both loops (87 VGPR, 5 waves per SIMD).  The chain launch goes first, so its waves are
+      // With a side stream these are two launches side by side: the rest then runs the batched
+      // kernel proper (71 VGPR, 7 waves per SIMD, batches of 48 hits / 24 path ends) instead of
+      // the small-batch loop inside the kernel that holds both (79 VGPR): 1920x1080 1.165 ->
+      // 1.12 ms.  The chain launch goes first, so its waves are
       // resident from the start.  RT_SPARSE_RANKS / RT_SPARSE_SHIFT / RT_TWO_LAUNCHES=0
       // override (measurements).
       static const int sparse_env = [] {
@@ -674,7 +676,7 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
         if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
         if (e != hipSuccess) return e;
         const dim3 chain_grid(Q.chain_ranks * 4u + extra, 1, 1), rest_grid((tiles.x - Q.chain_ranks) * 4u, 1, 1);
-        hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, kRegenPlain>), chain_grid, wave_block, 0, side->stream, P, S, F, Q);
+        hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenChain : kRegenPlain>), chain_grid, wave_block, 0, side->stream, P, S, F, Q);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
         Outputs T = Q;

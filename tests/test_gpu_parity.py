@@ -824,10 +824,12 @@ def test_fast_policy_ids_exact_on_random_scenes(oracle, accel):
 
 def test_regen_loop_forms_are_bit_identical():
     """k_mega_regen has two loops (the plain one and a throughput form that gathers path ends per
-    wave) and a mixed launch that runs the heaviest tiles through the first and the rest through
-    the second.  The choice is read once per process (RT_REGEN_FORM), so child processes render
-    the same frames with each form forced; images, ids and ray counts must be identical.  The
-    mixed form needs a measured tile order, which exists from the second launch on."""
+    wave) and a mixed form that runs the heaviest tiles through the first and the rest through
+    the second -- as two launches side by side, or as one kernel holding both loops -- with the
+    very heaviest tiles spread over waves of 32 / 16 / 8 lanes.  The choice is read once per
+    process (RT_REGEN_FORM and friends), so child processes render the same frames with each
+    form forced; images, ids and ray counts must be identical.  The mixed form needs a measured
+    tile order, which exists from the second launch on."""
     import os
     import subprocess
     import sys
@@ -850,12 +852,18 @@ def test_regen_loop_forms_are_bit_identical():
         "    print('DIGEST', m.hexdigest(), r.stats().rays)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
-    for form in ("plain", "batched", "mixed"):
-        env = dict(os.environ, RT_REGEN_FORM=form, RT_REGEN_CHAIN_DIV="4", PYTHONPATH=root)
+    variants = [dict(RT_REGEN_FORM="plain"), dict(RT_REGEN_FORM="batched"),
+                dict(RT_REGEN_FORM="mixed"),                                  # two launches, 16 tiles x 8 waves
+                dict(RT_REGEN_FORM="mixed", RT_SPARSE_RANKS="0"),             # two launches, no split
+                dict(RT_REGEN_FORM="mixed", RT_SPARSE_RANKS="5", RT_SPARSE_SHIFT="1"),
+                dict(RT_REGEN_FORM="mixed", RT_TWO_LAUNCHES="0"),             # one kernel with both loops
+                dict(RT_REGEN_FORM="mixed", RT_TWO_LAUNCHES="0", RT_SPARSE_RANKS="200", RT_SPARSE_SHIFT="2")]
+    for v in variants:
+        env = dict(os.environ, RT_REGEN_CHAIN_DIV="4", PYTHONPATH=root, **v)
         res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
         assert res.returncode == 0, res.stderr
         out.append([l for l in res.stdout.splitlines() if l.startswith("DIGEST")][0])
-    assert out[0] == out[1] == out[2], out
+    assert all(o == out[0] for o in out), out
 
 
 # ---------------------------------------------------------------- dielectric spheres (extension)

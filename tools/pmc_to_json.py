@@ -4,7 +4,10 @@ the file bench.py reads its `traffic` and counter ratios from.
 
     python tools/pmc_to_json.py profiles/r2 [tag shown in the source strings]
 
-Per workload and per launch of its dominant kernel (the variant with the most dispatches):
+Per workload and per step of its dominant kernel (the variant with the most dispatches; where a
+step is two kernels side by side -- the 1920x1080 default-scene frame: chain tiles and the rest --
+both have that count, their counts are added, and since a counter run serialises them the
+cycles of the step come from the measured step time in bench_cfgN.json at 2.4 GHz):
   hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; FETCH_SIZE reads half the
   bytes of wide coalesced reads on gfx950), cycles = GRBM_GUI_ACTIVE / 8 XCDs,
   valu_instructions_per_simd_cycle = SQ_INSTS_VALU / (1024 SIMDs * cycles),
@@ -43,17 +46,34 @@ for c in ("0", "1", "2", "3", "4"):
     kernels = parse(path)
     if not kernels:
         continue
-    name = max(kernels, key=lambda k: max((v[1] for v in kernels[k].values()), default=0))
-    k = {n: v[0] for n, v in kernels[name].items()}
+    count = lambda kk: max((v[1] for v in kernels[kk].values()), default=0)
+    top = max(count(kk) for kk in kernels)
+    names = [kk for kk in kernels if count(kk) == top and "true>" not in kk.split(",")[-1]] or \
+            [max(kernels, key=count)]
+    name = " + ".join(names)
+    k = {}
+    for kk in names:
+        for n, v in kernels[kk].items():
+            k[n] = k.get(n, 0.0) + v[0]
+    step_cycles = None
+    if len(names) > 1:
+        k.pop("GRBM_GUI_ACTIVE", None)
+        try:
+            line = [l for l in open(os.path.join(src, f"bench_cfg{c}.json")) if l.startswith("{")][-1]
+            step_cycles = json.loads(line)["config"]["ms_per_launch"] * 2.4e6
+        except (OSError, KeyError, IndexError, ValueError):
+            pass
     e = {"kernel": name, "source": f"{path} (rocprofv3 --pmc passes over `bench.py --config {c} --steps 4 "
                                    "--no-side-runs`, one run per pass; FETCH_SIZE doubled, gfx950)"}
     if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
         e["FETCH_SIZE_KB_per_launch"] = k["FETCH_SIZE"]
         e["WRITE_SIZE_KB_per_launch"] = k["WRITE_SIZE"]
         e["hbm_bytes_per_launch"] = int((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
-    if "GRBM_GUI_ACTIVE" in k:
-        cycles = k["GRBM_GUI_ACTIVE"] / 8.0
+    if "GRBM_GUI_ACTIVE" in k or step_cycles:
+        cycles = step_cycles or k["GRBM_GUI_ACTIVE"] / 8.0
         e["cycles_per_launch"] = cycles
+        if step_cycles:
+            e["cycles_source"] = "ms_per_launch of bench_cfg%s.json x 2.4 GHz (the kernels of a step overlap)" % c
         if "SQ_INSTS_VALU" in k:
             e["valu_instructions_per_launch"] = k["SQ_INSTS_VALU"]
             e["valu_instructions_per_simd_cycle"] = round(k["SQ_INSTS_VALU"] / (1024 * cycles), 4)
