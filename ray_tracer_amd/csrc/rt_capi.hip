@@ -135,6 +135,9 @@ struct rt_ctx {
 namespace {
 
 constexpr size_t kMaxPendingEvents = 512;
+// the context's counters: 256 bytes (segments, traversal tallies), then the spread segment counters
+constexpr size_t kRaySlotsOffset = 256;
+constexpr size_t kRayBytes = kRaySlotsOffset + (size_t)rt::kRaySlots * rt::kRaySlotStride;
 
 // folds finished event pairs into the statistics; keep_newest pairs may stay pending
 int collect_timing(rt_ctx *c, size_t keep_newest) {
@@ -273,7 +276,7 @@ static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
     return bail(e, "hipMalloc(rgba8)");
   if ((e = hipMalloc(&c->d_ids, c->n_pixels * sizeof(int32_t))) != hipSuccess)
     return bail(e, "hipMalloc(ids)");
-  if ((e = hipMalloc(&c->d_rays, 256)) != hipSuccess) return bail(e, "hipMalloc(rays)");
+  if ((e = hipMalloc(&c->d_rays, kRayBytes)) != hipSuccess) return bail(e, "hipMalloc(rays)");
   c->tiles_x = (cfg->width + 15u) / 16u;
   c->n_tiles = c->tiles_x * ((cfg->height + 15u) / 16u);
   if ((e = hipMalloc(&c->d_tile_cost, c->n_tiles * sizeof(uint32_t))) != hipSuccess)
@@ -341,7 +344,7 @@ int rt_clear(rt_ctx *c) {
   RT_HIP(hipMemsetAsync(c->d_accum, 0, c->n_pixels * sizeof(float4), c->stream));
   RT_HIP(hipMemsetAsync(c->d_rgba8, 0, c->n_pixels * sizeof(uchar4), c->stream));
   RT_HIP(hipMemsetAsync(c->d_ids, 0xff, c->n_pixels * sizeof(int32_t), c->stream));
-  RT_HIP(hipMemsetAsync(c->d_rays, 0, 256, c->stream));
+  RT_HIP(hipMemsetAsync(c->d_rays, 0, kRayBytes, c->stream));
   c->frames = 0;
   c->last_ms = c->total_ms = 0.f;
   c->last_launches = 0;
@@ -657,6 +660,7 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
   O.rgba8 = c->d_rgba8;
   O.ids = c->d_ids;
   O.rays = c->d_rays;
+  O.ray_slots = c->d_rays + kRaySlotsOffset / sizeof(unsigned long long);
   O.linear_accum = (c->flags & RT_FLAG_ACCUM_LINEAR) ? 1u : 0u;
   O.tiles_x = c->tiles_x;
   O.n_tiles = c->n_tiles;
@@ -778,9 +782,12 @@ static int rt_get_stats_impl(rt_ctx *c, rt_stats *out) {
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
   if (collect_timing(c, 0) != RT_OK) return RT_ERR_DEVICE;
-  unsigned long long counters[3] = {0, 0, 0};
-  RT_HIP(hipMemcpy(counters, c->d_rays, sizeof counters, hipMemcpyDeviceToHost));
-  const unsigned long long rays = counters[0];
+  // the segment count is rays[0] plus the spread counters the waves add to
+  std::vector<unsigned long long> counters(kRayBytes / sizeof(unsigned long long));
+  RT_HIP(hipMemcpy(counters.data(), c->d_rays, kRayBytes, hipMemcpyDeviceToHost));
+  unsigned long long rays = counters[0];
+  for (uint32_t i = 0; i < rt::kRaySlots; ++i)
+    rays += counters[(kRaySlotsOffset + (size_t)i * rt::kRaySlotStride) / sizeof(unsigned long long)];
   std::memset(out, 0, sizeof *out);
   out->rays = rays;
   out->frames = c->frames;
@@ -829,7 +836,8 @@ constexpr size_t kStaticOffMaterial = kStaticGeomBytes;
 constexpr size_t kStaticOffCost = (kStaticOffMaterial + kStaticMaterialBytes + 255u) / 256u * 256u;
 constexpr size_t kStaticOffOrder = kStaticOffCost + kStaticTileBytes;
 constexpr size_t kStaticOffRays = kStaticOffOrder + kStaticTileBytes;
-constexpr size_t kStaticBytes = kStaticOffRays + 256u;
+constexpr size_t kStaticOffRaySlots = kStaticOffRays + 256u;
+constexpr size_t kStaticBytes = kStaticOffRaySlots + (size_t)rt::kRaySlots * rt::kRaySlotStride;
 }  // namespace
 
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
@@ -907,6 +915,9 @@ int rt_render_static(const rt_static_job *job) {
   O.rgba8 = (uchar4 *)job->d_rgba8;
   O.ids = (int32_t *)job->d_ids;
   O.rays = rays;
+  // the waves count into spread counters (zero at load, cleared by every fold), which the end
+  // of the call adds into the caller's word (or the array's own)
+  O.ray_slots = (unsigned long long *)(base + kStaticOffRaySlots);
   O.linear_accum = (job->flags & RT_FLAG_ACCUM_LINEAR) ? 1u : 0u;
   O.tiles_x = tiles_x;
   O.n_tiles = n_tiles;
@@ -925,6 +936,8 @@ int rt_render_static(const rt_static_job *job) {
     O.tile_order = tile_order;
   }
   RT_HIP(rt::launch_megakernel(degenerate, strict, false, P, S, F, O, stream));
+  // (always, so that no call leaves counts behind for the next one)
+  RT_HIP(rt::launch_fold_rays(O.ray_slots, rays, stream));
   return RT_OK;
 }
 

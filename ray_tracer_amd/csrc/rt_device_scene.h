@@ -102,11 +102,17 @@ struct FrameSeq {
   uint32_t first, count, stride;
 };
 
+constexpr uint32_t kRaySlots = 1024, kRaySlotStride = 128;
 struct Outputs {
   float4 *accum;            // rgb += frame colour, a += 1, per frame
   uchar4 *rgba8;            // the shader's own 8-bit progressive image
   int32_t *ids;             // first-segment hit of sample 0 (last frame wins)
-  unsigned long long *rays; // += closest-hit searches
+  unsigned long long *rays; // += closest-hit searches ([1], [2]: traversal tallies of the counting kernels)
+  // Optional: kRaySlots counters, kRaySlotStride bytes apart, that the waves add their segment
+  // counts to instead of rays[0]; whoever reads the count adds them up.  Atomics on ONE address
+  // retire at ~80 per microsecond on the whole device, which bounded every launch of many short
+  // waves (1280x720 at 1 spp: 14,400 waves, 0.23 ms with the single counter, 0.075 ms with these).
+  unsigned long long *ray_slots;
   uint32_t linear_accum;    // 1: accumulate the linear mean, 0: the gamma-encoded colour
   // Launch order of the 16x16-pixel tiles (k_mega_regen, k_mega_sched): block b renders tile
   // tile_order[b].  The order is heaviest-first by the cost the previous launch of this

@@ -34,6 +34,8 @@ hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, c
 // and material arrays
 hipError_t launch_repack_spheres(const void *spheres64, uint32_t n, uint32_t n_geom, float4 *geom,
                                  float4 *material, hipStream_t stream);
+// adds the kRaySlots spread counters up into *total and clears them
+hipError_t launch_fold_rays(unsigned long long *slots, unsigned long long *total, hipStream_t stream);
 // tile costs of the last launch -> heaviest-first launch order; clears the costs
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_mega_nested(Params P, Scene S, FrameSeq
     }
   }
   uint32_t wsum = wave_sum_u32(nrays);
-  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+  if ((threadIdx.x & 63u) == 0 && wsum) add_rays(O, wave_index(), wsum);
   if constexpr (COUNT) {
     const uint32_t a = wave_sum_u32(cnt_nodes), b = wave_sum_u32(cnt_prims);
     if ((threadIdx.x & 63u) == 0) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint
   const uint32_t wsum = wave_sum_u32(nrays);
   const uint32_t wmax = wave_max_u32(nrays);
   if ((threadIdx.x & 63u) == 0) {
-    if (wsum && !RT_IS_PROBE) atomicAdd(O.rays, (unsigned long long)wsum);
+    if (wsum && !RT_IS_PROBE) add_rays(O, wave_index(), wsum);
     if (O.tile_cost) atomicMax(O.tile_cost + tile, wmax);
   }
 }
@@ -661,7 +661,9 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
         const char *e = getenv("RT_TWO_LAUNCHES");
         return !(e && e[0] == '0');
       }();
-      const bool two = B && side && two_env && Q.chain_ranks < tiles.x;
+      // (forking to the side stream and joining costs ~30 us: 1280x720 at 1 spp takes 0.043 ms as
+      // one launch and 0.075 ms as two, so only launches with long chains are split)
+      const bool two = B && side && two_env && Q.chain_ranks < tiles.x && (uint64_t)P.n_spp * F.count >= 32u;
       const bool few = O.n_tiles <= RT_SPARSE_FEW_TILES;
       // (measured optima: one launch 3 tiles x 4 waves, two launches 2 tiles x 8; launches that
       // never fill the device 16 tiles x 8)

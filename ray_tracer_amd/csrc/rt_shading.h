@@ -630,4 +630,15 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
+// a wave's (or block's) path segments into the launch's count; index: any number that differs
+// between the waves that finish at about the same time
+__device__ __forceinline__ void add_rays(const Outputs &O, uint32_t index, uint32_t n) {
+  unsigned long long *p = O.ray_slots ? O.ray_slots + (size_t)(index & (kRaySlots - 1u)) * (kRaySlotStride / 8u)
+                                      : O.rays;
+  atomicAdd(p, (unsigned long long)n);
+}
+__device__ __forceinline__ uint32_t wave_index() {
+  return (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+}
+
 }  // namespace rt

@@ -150,6 +150,29 @@ hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, c
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(1024) void k_fold_rays(unsigned long long *__restrict__ slots,
+                                                    unsigned long long *__restrict__ total) {
+  static_assert(kRaySlots == 1024, "one thread per counter");
+  __shared__ unsigned long long part[16];
+  unsigned long long *p = slots + (size_t)threadIdx.x * (kRaySlotStride / 8u);
+  unsigned long long v = *p;
+  *p = 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long sum = 0;
+    for (int i = 0; i < 16; ++i) sum += part[i];
+    if (sum) atomicAdd(total, sum);
+  }
+}
+
+hipError_t launch_fold_rays(unsigned long long *slots, unsigned long long *total, hipStream_t stream) {
+  hipLaunchKernelGGL(k_fold_rays, dim3(1), dim3(1024), 0, stream, slots, total);
+  return hipGetLastError();
+}
+
 // Launch order for the next megakernel launch: tiles sorted by descending cost with one
 // counting sort (4096 buckets; costs are scaled down by a power of two when the largest
 // exceeds the bucket range), done by a single block.  Ties land in arbitrary order, which

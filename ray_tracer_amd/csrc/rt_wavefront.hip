@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(Params P, Scene S, WfView V, u
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const uint32_t *cnt = V.counts + 4u * (slot & 3u);
     const uint32_t traced = cnt[1] + cnt[2];
-    if (traced) atomicAdd(O.rays, (unsigned long long)traced);
+    if (traced) add_rays(O, slot, traced);
   }
   const uint2 fill = V.slice[blockIdx.x];
   const uint32_t n_hit = fill.x, first_miss = (256u * E) - fill.y;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_wf_drain(Params P, Scene S, WfView V, u
     if (id0 != -2) O.ids[pix] = id0;
   }
   const uint32_t wsum = wave_sum_u32(nrays);
-  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+  if ((threadIdx.x & 63u) == 0 && wsum) add_rays(O, wave_index(), wsum);
 }
 
 // The drain launch for LBVH scenes: the same resumption, in k_mega_sched's wave-scheduled
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_drain_tree(Params 
     }
   }
   const uint32_t wsum = wave_sum_u32(nrays);
-  if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(O.rays, (unsigned long long)wsum);
+  if ((threadIdx.x & 63u) == 0 && wsum) add_rays(O, wave_index(), wsum);
 }
 
 // ---- host side ---------------------------------------------------------------------
