@@ -95,6 +95,7 @@ struct rt_ctx {
   float mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0};  // bounds of the mesh vertices
   float mesh_material[12] = {0};
 
+  uint32_t *d_mesh_report = nullptr;  // 7 words an upload's device checks report in (kept between uploads)
   float *d_ior = nullptr;        // per sphere, > 0: dielectric (optional; null: none)
   bool have_ior = false;
 
@@ -324,6 +325,7 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_tri) hipFree(c->d_tri);
   if (c->d_tri_spare) hipFree(c->d_tri_spare);
   if (c->d_ior) hipFree(c->d_ior);
+  if (c->d_mesh_report) hipFree(c->d_mesh_report);
   if (c->d_texels) hipFree(c->d_texels);
   if (c->d_tex_lut) hipFree(c->d_tex_lut);
   if (c->d_tex) hipFree(c->d_tex);
@@ -476,9 +478,11 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   if (n_triangles) {
     float *d_v = nullptr;
-    uint32_t *d_i = nullptr, *d_report = nullptr;
+    uint32_t *d_i = nullptr;
     uint32_t report[7];
-    hipError_t e = hipMalloc(&d_report, sizeof report);
+    // (no allocation or release per upload where it can be helped: hipFree waits for the device)
+    hipError_t e = c->d_mesh_report ? hipSuccess : hipMalloc(&c->d_mesh_report, sizeof report);
+    uint32_t *d_report = c->d_mesh_report;
     // the triangle array of the previous mesh is reused when the new one has as many triangles
     // and a spare exists (a mesh re-uploaded every frame then allocates nothing here)
     if (e == hipSuccess) {
@@ -514,7 +518,6 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
       hipFree(d_v);
       hipFree(d_i);
     }
-    hipFree(d_report);
     if (e != hipSuccess) {
       hipFree(new_tri);
       return fail(RT_ERR_DEVICE, "rt_set_mesh: %s", hipGetErrorString(e));
@@ -795,7 +798,7 @@ static int rt_get_stats_impl(rt_ctx *c, rt_stats *out) {
   out->total_render_ms = c->total_ms;
   out->last_launches = c->last_launches;
   out->bvh_nodes = c->use_bvh ? c->bvh.n_nodes : 0u;
-  out->last_build_ms = c->bvh.last_build_ms;
+  out->last_build_ms = c->bvh.build_ms();
   out->bvh_height = c->use_bvh ? c->bvh.height : 0u;
   out->bvh_nodes_visited = counters[1];
   out->bvh_spheres_tested = counters[2];

@@ -22,7 +22,9 @@ struct Lbvh {
   uint32_t capacity = 0;           // spheres the arrays above can hold
   uint32_t height = 0;             // longest root-to-leaf path in edges = traversal stack bound
   uint32_t refit_passes = 0;
-  float last_build_ms = 0.f;
+  float last_build_ms = 0.f;     // use build_ms()
+  bool timing_pending = false;
+  float build_ms();              // device time of the last build (waits for it if it is still running)
 
   struct Work;
   Work *work = nullptr;            // build workspace, kept between builds

@@ -499,6 +499,10 @@ struct Lbvh::Work {
   int *left = nullptr, *right = nullptr, *parent = nullptr, *leaf_parent = nullptr;
   int *range_first = nullptr, *range_count = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // what the device holds of the host-made inputs (uploads of unchanged content are skipped: a
+  // blocking copy per rebuild is a tenth of a small rebuild)
+  std::vector<float> up_cr, up_large_geom;
+  std::vector<uint32_t> up_large_prim;
 };
 
 void Lbvh::release() {
@@ -565,6 +569,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     if (work->slab) hipFree(work->slab);
     work->slab = nullptr;
     work->capacity = 0;
+    work->up_cr.clear();  // (lived in the slab)
     const size_t f4 = align256((size_t)n * sizeof(float4)), u4 = align256((size_t)n * sizeof(uint32_t));
     const size_t hist = align256((size_t)256 * nblk * sizeof(uint32_t));
     const size_t sums = align256(((size_t)256 * nblk / kScanTile + 2) * sizeof(uint32_t));
@@ -645,8 +650,12 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
       BVH_HIP(hipMalloc((void **)&large_geom, kMaxLargeSpheres * sizeof(float4)));
       BVH_HIP(hipMalloc((void **)&large_prim, kMaxLargeSpheres * sizeof(uint32_t)));
     }
-    BVH_HIP(hipMemcpy(large_geom, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
-    BVH_HIP(hipMemcpy(large_prim, li.data(), li.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (lg != w.up_large_geom || li != w.up_large_prim) {
+      BVH_HIP(hipMemcpy(large_geom, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
+      BVH_HIP(hipMemcpy(large_prim, li.data(), li.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      w.up_large_geom = lg;
+      w.up_large_prim = li;
+    }
   }
   float rmax_small = 0.f;
   for (int k = 0; k < 3; ++k) bp.blo[k] = bp.bhi[k] = cam[k];
@@ -671,10 +680,11 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
 
   // ---- device build ----------------------------------------------------------------------
   BVH_HIP(hipEventRecord(w.ev0, stream));
-  if (n_spheres) {
+  if (n_spheres && cr != w.up_cr) {
     BVH_HIP(hipMemcpyAsync(w.cr, cr.data(), (size_t)n_spheres * 4 * sizeof(float),
                            hipMemcpyHostToDevice, stream));
     BVH_HIP(hipStreamSynchronize(stream));  // cr (pageable host memory) must outlive the copy
+    w.up_cr = cr;
   }
   BVH_HIP(hipMemsetAsync(w.cbounds, 0xff, 3 * sizeof(uint32_t), stream));      // running minima
   BVH_HIP(hipMemsetAsync(w.cbounds + 3, 0x00, 3 * sizeof(uint32_t), stream));  // running maxima
@@ -717,31 +727,46 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     rv.stamp = w.stamp; rv.box_lo = w.box_lo; rv.box_hi = w.box_hi;
     rv.nodes = nodes;
     rv.n_internal = (int)(n - 1);
+    // Passes are launched in rounds, each followed by one look at the root (its stamp, and the
+    // height that comes with its box): as many as the previous build needed to begin with, since
+    // a rebuild of the same mesh in another pose needs about as many, then four at a time.
     uint32_t pass = 1;
-    bool done = false;
-    while (!done) {
-      for (int k = 0; k < 8; ++k, ++pass)
+    uint32_t round = refit_passes ? refit_passes : 8u;
+    for (;;) {
+      for (uint32_t k = 0; k < round; ++k, ++pass)
         hipLaunchKernelGGL(k_refit, dim3(blocks_i), dim3(kThreads), 0, stream, rv, pass);
       uint32_t root_stamp = 0;
+      float4 root_lo;
       BVH_HIP(hipMemcpyAsync(&root_stamp, w.stamp, sizeof root_stamp, hipMemcpyDeviceToHost, stream));
+      BVH_HIP(hipMemcpyAsync(&root_lo, w.box_lo, sizeof root_lo, hipMemcpyDeviceToHost, stream));
       BVH_HIP(hipStreamSynchronize(stream));
-      done = root_stamp != 0u;
-      if (!done && pass > 4u * 65536u) {
+      if (root_stamp != 0u) {
+        refit_passes = root_stamp;  // the pass that finished the root
+        height = (uint32_t)root_lo.w;
+        break;
+      }
+      if (pass > 4u * 65536u) {
         if (err) *err = "bounds propagation did not reach the root";
         return -2;
       }
+      round = 4u;
     }
-    refit_passes = pass - 1;
-    float4 root_lo;
-    BVH_HIP(hipMemcpyAsync(&root_lo, w.box_lo, sizeof root_lo, hipMemcpyDeviceToHost, stream));
-    BVH_HIP(hipStreamSynchronize(stream));
-    height = (uint32_t)root_lo.w;
   }
   BVH_HIP(hipEventRecord(w.ev1, stream));
-  BVH_HIP(hipEventSynchronize(w.ev1));
-  BVH_HIP(hipEventElapsedTime(&last_build_ms, w.ev0, w.ev1));
+  timing_pending = true;  // read by build_ms(), so that no build waits for its own end
   BVH_HIP(hipGetLastError());
   return 0;
+}
+
+float Lbvh::build_ms() {
+  if (timing_pending && work) {
+    float ms = 0.f;
+    if (hipEventSynchronize(work->ev1) == hipSuccess &&
+        hipEventElapsedTime(&ms, work->ev0, work->ev1) == hipSuccess)
+      last_build_ms = ms;
+    timing_pending = false;
+  }
+  return last_build_ms;
 }
 
 int Lbvh::download(std::vector<BvhNode> *out_nodes, std::vector<uint32_t> *out_prims) const {
