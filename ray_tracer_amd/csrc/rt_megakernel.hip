@@ -144,10 +144,12 @@ __device__ __forceinline__ uint32_t tile_thread() {
 // scene came out 3 % slower (1.245 against 1.209 ms; the chain of the slowest wave is that
 // sensitive to how the compiler lays out the loop).
 #define RT_IS_PROBE (PROBE || O.probe)
+// cost: what the wave reports as its tile's cost (the largest report of a tile counts); 0: the
+// segments of its slowest pixel
 template <bool PROBE>
-__device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint32_t nrays) {
+__device__ __forceinline__ void tally_wave(const Outputs &O, uint32_t tile, uint32_t nrays, uint32_t cost = 0) {
   const uint32_t wsum = wave_sum_u32(nrays);
-  const uint32_t wmax = wave_max_u32(nrays);
+  const uint32_t wmax = cost ? cost : wave_max_u32(nrays);
   if ((threadIdx.x & 63u) == 0) {
     if (wsum && !RT_IS_PROBE) add_rays(O, wave_index(), wsum);
     if (O.tile_cost) atomicMax(O.tile_cost + tile, wmax);
@@ -485,6 +487,9 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
   pixel_of_tile(tile, O.tiles_x, tile_thread<kTileBlock>(), px, py);
 #endif
   uint32_t nrays = 0;
+#ifdef RT_MEASURE_TIMELINE
+  const unsigned long long t_begin_sched = wall_clock64();
+#endif
   bool active = px < P.width && py < P.height && F.count;
   const f3 base = pixel_direction(P, px, py);
   constexpr bool kIdsEarly = true;
@@ -501,7 +506,14 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
   Search<APPROX> Q;
   search_begin<DIEL>(S, o, d, skip, Q);
 
+  // The tile's cost for the next launch's order is the number of steps the wave took, not the
+  // segments of its slowest pixel: with a tree the time of a wave follows the nodes its rays
+  // visit (on the terrain the waves at the horizon take 2 ms for 20 segments per pixel, the
+  // median wave 0.07 ms), and ordered by segments those waves started 2.5 ms into a 4.4 ms
+  // launch and ran on alone for its last quarter.
+  uint32_t steps = 0;
   while (true) {
+    ++steps;
     const bool want_inner = active && Q.node >= 0;
     const bool want_shade = active && Q.node == kSearchOver;
     const bool want_leaf = active && !want_inner && !want_shade;
@@ -569,7 +581,22 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
       if (active) search_begin<DIEL>(S, o, d, skip, Q);
     }
   }
-  tally_wave<PROBE>(O, tile, nrays);
+  tally_wave<PROBE>(O, tile, nrays, steps);
+#ifdef RT_MEASURE_TIMELINE
+  {  // as in k_mega_regen: the wave's begin / end / segments / slowest lane where the ids would go
+    const uint32_t wsum = wave_sum_u32(nrays), wmax = wave_max_u32(nrays);
+    if ((threadIdx.x & 63u) == 0) {
+      const unsigned long long t_end = wall_clock64();
+      int *rec = O.ids + 6u * (size_t)(tile * 4u + ((blockIdx.x >> 3) & 3u));
+      rec[0] = (int)(uint32_t)t_begin_sched;
+      rec[1] = (int)(uint32_t)(t_begin_sched >> 32);
+      rec[2] = (int)(uint32_t)t_end;
+      rec[3] = (int)(uint32_t)(t_end >> 32);
+      rec[4] = (int)wsum;
+      rec[5] = (int)wmax;
+    }
+  }
+#endif
 }
 
 template <bool STRICT, bool BVH, int EXT, bool APPROX>

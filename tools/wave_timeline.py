@@ -5,9 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ray_tracer_amd as rt
 w, h = 1920, 1080
-ubo = rt.make_ubo(w, h, 64, 25)
+scene = sys.argv[1] if len(sys.argv) > 1 else "default"   # default | terrain | grid
+ubo = rt.make_ubo(w, h, 64, 25) if scene == "default" else rt.make_ubo(w, h, 8, 8 if scene == "terrain" else 25)
 with rt.Renderer(w, h) as r:
-    r.set_params(ubo); r.set_spheres(rt.default_scene())
+    r.set_params(ubo)
+    if scene == "terrain":
+        r.set_spheres(rt.default_scene()[:2])
+        r.set_mesh(*rt.terrain_mesh(709), rt.matte(0.55, 0.5, 0.4, smoothness=0.7, specular_probability=0.15))
+    elif scene == "grid":
+        r.set_spheres(rt.grid_spheres_scene(10000))
+    else:
+        r.set_spheres(rt.default_scene())
     r.render(0, 1, 1); r.sync()
     r.render(1, 1, 1); r.sync()
     r.render(2, 1, 1); r.sync()
