@@ -4,21 +4,26 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ray_tracer_amd as rt
-w, h = 1920, 1080
-scene = sys.argv[1] if len(sys.argv) > 1 else "default"   # default | terrain | grid
-ubo = rt.make_ubo(w, h, 64, 25) if scene == "default" else rt.make_ubo(w, h, 8, 8 if scene == "terrain" else 25)
+scene = sys.argv[1] if len(sys.argv) > 1 else "default"   # default | terrain | grid | glass4k
+w, h = (3840, 2160) if scene == "glass4k" else (1920, 1080)
+frames = 8 if scene == "glass4k" else 1
+ubo = rt.make_ubo(w, h, 64, 25) if scene == "default" else rt.make_ubo(w, h, 32, 25) if scene == "glass4k" else \
+    rt.make_ubo(w, h, 8, 8 if scene == "terrain" else 25)
 with rt.Renderer(w, h) as r:
     r.set_params(ubo)
-    if scene == "terrain":
+    if scene == "glass4k":
+        sph, ior = rt.grid_spheres_scene_glass(10000)
+        r.set_spheres(sph); r.set_dielectric(ior)
+    elif scene == "terrain":
         r.set_spheres(rt.default_scene()[:2])
         r.set_mesh(*rt.terrain_mesh(709), rt.matte(0.55, 0.5, 0.4, smoothness=0.7, specular_probability=0.15))
     elif scene == "grid":
         r.set_spheres(rt.grid_spheres_scene(10000))
     else:
         r.set_spheres(rt.default_scene())
-    r.render(0, 1, 1); r.sync()
-    r.render(1, 1, 1); r.sync()
-    r.render(2, 1, 1); r.sync()
+    r.render(0, frames, 1); r.sync()
+    r.render(frames, frames, 1); r.sync()
+    r.render(2 * frames, frames, 1); r.sync()
     ms = r.stats().last_render_ms
     ids = r.read_primary_ids().reshape(-1)
 n_waves = ((w + 15) // 16) * ((h + 15) // 16) * 4
@@ -34,9 +39,10 @@ print("duration us: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (dur.mean()
 print("sum of wave durations / (span * 6144 slots) = %.2f" % (dur.sum() / (e.max() * 6144)))
 for q in (0.5, 0.75, 0.9, 0.95, 0.99, 1.0):
     print(f"  {q:.2f} of waves ended by {np.quantile(e, q):.0f} us")
-act = np.zeros(int(e.max()) + 2)
-for x, y in zip(b.astype(int), e.astype(int)):
-    act[x:y + 1] += 1
+act = np.zeros(int(e.max()) + 3)
+np.add.at(act, b.astype(int), 1)
+np.add.at(act, e.astype(int) + 1, -1)
+act = np.cumsum(act)
 step = max(1, len(act) // 24)
 print("resident waves over time:", " ".join(str(int(act[i:i + step].mean())) for i in range(0, len(act), step)))
 late = np.argsort(-e)[:8]
