@@ -292,7 +292,38 @@ static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
     return bail(e, "hipEventCreate(fork)");
   if ((e = hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming)) != hipSuccess)
     return bail(e, "hipEventCreate(join)");
-  c->have_side = true;
+  // Two launches side by side only pay if the two streams really run side by side.  Streams
+  // share a few hardware queues, and two streams that landed on one queue (or run under a tool
+  // that serialises kernels) would make such a launch the SUM of its two kernels, nearly twice
+  // the single-kernel form.  So: two 200 us one-wave kernels, forked and joined exactly like a
+  // render (which costs ~30 us by itself); side by side they take ~0.23 ms, in a row 0.43.
+  {
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    float ms = 1e9f;
+    e = hipEventCreate(&t0);
+    if (e == hipSuccess) e = hipEventCreate(&t1);
+    // (the first launch of a process also loads the code and wakes the queues: not timed)
+    if (e == hipSuccess) e = rt::launch_spin(1, c->side.stream);
+    if (e == hipSuccess) e = rt::launch_spin(1, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->side.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipEventRecord(t0, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(c->side.fork, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->side.stream, c->side.fork, 0);
+    if (e == hipSuccess) e = rt::launch_spin(20000, c->side.stream);
+    if (e == hipSuccess) e = hipEventRecord(c->side.join, c->side.stream);
+    if (e == hipSuccess) e = rt::launch_spin(20000, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->side.join, 0);
+    if (e == hipSuccess) e = hipEventRecord(t1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(t1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t0, t1);
+    if (t0) hipEventDestroy(t0);
+    if (t1) hipEventDestroy(t1);
+    if (e != hipSuccess) return bail(e, "side stream check");
+    c->have_side = ms < 0.32f;
+    if (std::getenv("RT_SIDE_STREAM_REPORT")) std::fprintf(stderr, "rt_create: side stream check %.3f ms\n", ms);
+    if (const char *env = std::getenv("RT_SIDE_STREAM")) c->have_side = env[0] != '0';
+  }
   if (const char *env = std::getenv("RT_TILE_ORDER")) c->use_tile_order = env[0] != '0';
   if (const char *env = std::getenv("RT_TILE_PROBE")) c->use_probe = env[0] != '0';
   int rc = rt_clear(c);

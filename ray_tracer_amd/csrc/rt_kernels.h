@@ -38,6 +38,8 @@ hipError_t launch_repack_spheres(const void *spheres64, uint32_t n, uint32_t n_g
 hipError_t launch_fold_rays(unsigned long long *slots, unsigned long long *total, hipStream_t stream);
 // tile costs of the last launch -> heaviest-first launch order; clears the costs
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
+// a one-wave kernel that waits for `ticks` ticks of the 100 MHz wall clock (stream placement checks)
+hipError_t launch_spin(unsigned long long ticks, hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,
                              hipStream_t stream);
 

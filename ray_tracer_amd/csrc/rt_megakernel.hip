@@ -672,7 +672,7 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
       // With a side stream these are two launches side by side: the rest then runs the batched
       // kernel proper (71 VGPR, 7 waves per SIMD, batches of 48 hits / 24 path ends) instead of
       // the small-batch loop inside the kernel that holds both (79 VGPR): 1920x1080 1.165 ->
-      // 1.12 ms.  The chain launch goes first, so its waves are
+      // 1.12 ms.  The chain launch goes first and on the caller's stream, so its waves are
       // resident from the start.  RT_SPARSE_RANKS / RT_SPARSE_SHIFT / RT_TWO_LAUNCHES=0
       // override (measurements).
       static const int sparse_env = [] {
@@ -705,19 +705,23 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
         if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
         if (e != hipSuccess) return e;
         const dim3 chain_grid(Q.chain_ranks * 4u + extra, 1, 1), rest_grid((tiles.x - Q.chain_ranks) * 4u, 1, 1);
-        hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenChain : kRegenPlain>), chain_grid, wave_block, 0, side->stream, P, S, F, Q);
+        // The chain launch stays on the caller's stream, where nothing holds it up, and the
+        // rest goes to the side stream, which first has to see the fork event: whichever way
+        // the two queues are served, the chain waves are not the ones that start late (the
+        // other way round the launch took 2.0 instead of 1.1 ms under a kernel tracer).
+        hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenChain : kRegenPlain>), chain_grid, wave_block, 0, stream, P, S, F, Q);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
         Outputs T = Q;
         T.rank_base = Q.chain_ranks;
         T.sparse_ranks = 0;
         if (e == hipSuccess) {
-          hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain>), rest_grid, wave_block, 0, stream, P, S, F, T);
+          hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain>), rest_grid, wave_block, 0, side->stream, P, S, F, T);
           e = hipGetLastError();
         }
         // the caller's stream continues only when both launches are done (also after a failure
         // above: whatever reached the side stream is joined)
-        const hipError_t ej = hipStreamWaitEvent(stream, side->join, 0);
+        hipError_t ej = hipEventRecord(side->join, side->stream);
+        if (ej == hipSuccess) ej = hipStreamWaitEvent(stream, side->join, 0);
         return e != hipSuccess ? e : ej;
       }
       const dim3 mixed_tiles(wave_tiles.x + extra, 1, 1);
