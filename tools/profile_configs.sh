@@ -1,7 +1,9 @@
 # rocprofv3 evidence for every bench.py workload: bash tools/profile_configs.sh <tag> [configs]
 # (run on the GPU box from the repository root; writes gpurun_out/prof_<tag>/)
-#   kernel_stats_cfgN.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --config N`
-#   bench_cfgN.json         the JSON line of that same run
+#   bench_cfgN.json         the JSON line of `python3 bench.py --config N`, run on its own
+#   kernel_stats_cfgN.csv   rocprofv3 --kernel-trace --stats of the same command
+#   bench_cfgN.traced.json  the JSON line of that traced run (the tracer costs launches of many
+#                           small kernels a few per cent)
 #   pmc_cfgN.txt            counter passes of the dominant kernel (one rocprofv3 run per pass)
 tag=${1:-x}
 configs=${2:-"1 2 3 4"}
@@ -10,7 +12,8 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in $configs; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -- python3 $root/bench.py --config $c > $out/bench_cfg$c.json 2> $out/bench_cfg$c.err || exit 1
+  timeout -k 10 400 python3 $root/bench.py --config $c > $out/bench_cfg$c.json 2> $out/bench_cfg$c.err || exit 1
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -- python3 $root/bench.py --config $c --no-cpu-baseline > $out/bench_cfg$c.traced.json 2>> $out/bench_cfg$c.err || exit 1
   find $out/stats_$c -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_cfg$c.csv
   rm -rf $out/stats_$c
 done
