@@ -119,6 +119,10 @@ struct rt_ctx {
   uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr;
   uint32_t tiles_x = 0, n_tiles = 0;
   bool order_valid = false, use_tile_order = true, use_probe = true;
+  // d_tile_order holds two tables of n_tiles: the order by the tiles' own costs, and the order by
+  // the largest cost in each tile's 3x3 neighbourhood, which LBVH scenes use while the geometry
+  // has changed since the costs were measured (a mesh re-uploaded every frame)
+  bool order_moved = false;
   // the order is refreshed after launches 1, 2, 4, 8, then every 16th since the last change
   // of scene or parameters; in between the costs keep accumulating (atomicMax)
   uint32_t order_interval = 1, launches_since_order = 0;
@@ -282,7 +286,7 @@ static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
   c->n_tiles = c->tiles_x * ((cfg->height + 15u) / 16u);
   if ((e = hipMalloc(&c->d_tile_cost, c->n_tiles * sizeof(uint32_t))) != hipSuccess)
     return bail(e, "hipMalloc(tile cost)");
-  if ((e = hipMalloc(&c->d_tile_order, c->n_tiles * sizeof(uint32_t))) != hipSuccess)
+  if ((e = hipMalloc(&c->d_tile_order, 2 * (size_t)c->n_tiles * sizeof(uint32_t))) != hipSuccess)
     return bail(e, "hipMalloc(tile order)");
   if ((e = hipMemsetAsync(c->d_tile_cost, 0, c->n_tiles * sizeof(uint32_t), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(tile cost)");
@@ -484,6 +488,7 @@ static int rt_set_spheres_impl(rt_ctx *c, const void *spheres64, uint32_t count)
                      hipMemcpyHostToDevice));
   }
   c->n_spheres = count;
+  c->order_moved = true;  // the costs on record belong to the geometry that is being replaced
   c->order_interval = 1;
   c->launches_since_order = 0;
   int rc = rebuild_accel(c);
@@ -583,6 +588,7 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
   std::memcpy(c->mesh_lo, lo, sizeof lo);
   std::memcpy(c->mesh_hi, hi, sizeof hi);
   c->n_tris = n_triangles;
+  c->order_moved = true;  // the costs on record belong to the geometry that is being replaced
   c->order_interval = 1;
   c->launches_since_order = 0;
   if (!c->d_material) {  // no spheres uploaded yet (or an upload failed half way): an empty sphere set
@@ -700,7 +706,8 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
   O.n_tiles = c->n_tiles;
   if (c->use_tile_order) {
     O.tile_cost = c->d_tile_cost;
-    O.tile_order = c->order_valid ? c->d_tile_order : nullptr;
+    O.tile_order = !c->order_valid ? nullptr
+                   : (c->order_moved && c->use_bvh) ? c->d_tile_order + c->n_tiles : c->d_tile_order;
   }
   const rt::Scene S = scene_view(c);
   const bool strict = (c->flags & RT_FLAG_STRICT_MATH) != 0;
@@ -727,9 +734,12 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
     probe_out.probe = 1u;
     he = rt::launch_megakernel(false, strict, c->use_bvh, probe_params, S, rt::FrameSeq{first_frame, 1u, 1u},
                                probe_out, c->stream);
-    if (he == hipSuccess) he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, c->stream);
+    if (he == hipSuccess)
+      he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, c->stream,
+                                 c->d_tile_order + c->n_tiles, c->tiles_x);
     if (he == hipSuccess) {
       c->order_valid = true;
+      c->order_moved = false;
       O.tile_order = c->d_tile_order;
     }
   }
@@ -751,8 +761,12 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
   if (he == hipSuccess && rc == RT_OK && ordered && ++c->launches_since_order >= c->order_interval) {
     // what the launches since the last refresh measured becomes the next launch's order
     // (outside the timed pair)
-    he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, c->stream);
-    if (he == hipSuccess) c->order_valid = true;
+    he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, c->stream,
+                               c->d_tile_order + c->n_tiles, c->tiles_x);
+    if (he == hipSuccess) {
+      c->order_valid = true;
+      c->order_moved = false;
+    }
     c->launches_since_order = 0;
     if (c->order_interval < 16u) c->order_interval *= 2u;
   }

@@ -37,7 +37,10 @@ hipError_t launch_repack_spheres(const void *spheres64, uint32_t n, uint32_t n_g
 // adds the kRaySlots spread counters up into *total and clears them
 hipError_t launch_fold_rays(unsigned long long *slots, unsigned long long *total, hipStream_t stream);
 // tile costs of the last launch -> heaviest-first launch order; clears the costs
-hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
+// order_near (optional, needs tiles_x): the same with every tile ranked by the largest cost among
+// itself and its eight neighbours
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream,
+                             uint32_t *order_near = nullptr, uint32_t tiles_x = 0);
 // a one-wave kernel that waits for `ticks` ticks of the 100 MHz wall clock (stream placement checks)
 hipError_t launch_spin(unsigned long long ticks, hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,

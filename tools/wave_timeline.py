@@ -23,6 +23,8 @@ with rt.Renderer(w, h) as r:
         r.set_spheres(rt.default_scene())
     r.render(0, frames, 1); r.sync()
     r.render(frames, frames, 1); r.sync()
+    if len(sys.argv) > 2 and scene == "terrain":   # a new pose of the surface before the recorded launch, as in bench.py
+        r.set_mesh(*rt.terrain_mesh(709, phase=float(sys.argv[2])), rt.matte(0.55, 0.5, 0.4, smoothness=0.7, specular_probability=0.15))
     r.render(2 * frames, frames, 1); r.sync()
     ms = r.stats().last_render_ms
     ids = r.read_primary_ids().reshape(-1)
