@@ -83,10 +83,11 @@ __device__ __forceinline__ uint32_t pcg_jump(uint32_t s, int k) {
   return s * A[k] + C[k];
 }
 // randomValue of a state that has already been advanced
-__device__ __forceinline__ float pcg_output_float(uint32_t s) {
+__device__ __forceinline__ uint32_t pcg_output_bits(uint32_t s) {
   uint32_t r = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
-  return (float)((r >> 22) ^ r) * 0x1p-32f;
+  return (r >> 22) ^ r;
 }
+__device__ __forceinline__ float pcg_output_float(uint32_t s) { return (float)pcg_output_bits(s) * 0x1p-32f; }
 
 // ---- strict polynomial kernels ---------------------------------------------
 namespace pm {
@@ -223,6 +224,9 @@ struct Math<true> {
   static __device__ __forceinline__ float box_cos(float u) { return pm::cos(6.283185f * u); }
   // -2*log(u)  (ray_tracing.comp:123)
   static __device__ __forceinline__ float neg2log(float u) { return -2.0f * pm::log(u); }
+  // the same two for a draw still in its 32 bits (randomValue = bits / 2^32)
+  static __device__ __forceinline__ float box_cos_bits(uint32_t r) { return box_cos((float)r * 0x1p-32f); }
+  static __device__ __forceinline__ float neg2log_bits(uint32_t r) { return neg2log((float)r * 0x1p-32f); }
   // angle = u*2*PI  (ray_tracing.comp:135-136)
   static __device__ __forceinline__ void circle(float u, float &c, float &s) {
     pm::sincos((u * 2.0f) * 3.1415926f, s, c);
@@ -243,6 +247,19 @@ struct Math<false> {
   static __device__ __forceinline__ float box_cos(float u) { return __builtin_amdgcn_cosf(u); }
   static __device__ __forceinline__ float neg2log(float u) {
     return -1.38629436f * __builtin_amdgcn_logf(u);  // -2 ln2 * log2(u)
+  }
+  // For a draw still in its 32 bits the scale by 2^-32 folds away.  Cosine: the cosine unit works
+  // in revolutions, so 1 + (bits >> 9) / 2^23, assembled by ONE funnel shift (exponent of 1.0
+  // over the top 23 bits), has the cosine of bits / 2^32 to within 2^-23 of a revolution.
+  // Logarithm: -2 ln(bits / 2^32) = -2 ln2 (log2(bits) - 32), one multiply-add after the log
+  // unit (64 ln2 is 32 x the other constant, exact, so a draw of 1.0 still gives exactly 0);
+  // near 1.0 the result is only good to ~4e-6 absolute and may come out a hair below zero, hence
+  // the magnitude (it becomes an operand modifier of the square root that follows).
+  static __device__ __forceinline__ float box_cos_bits(uint32_t r) {
+    return __builtin_amdgcn_cosf(__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, r, 9u)));
+  }
+  static __device__ __forceinline__ float neg2log_bits(uint32_t r) {
+    return __builtin_fabsf(__builtin_fmaf(__builtin_amdgcn_logf((float)r), -1.38629436f, 32.0f * 1.38629436f));
   }
   static __device__ __forceinline__ void circle(float u, float &c, float &s) {
     c = __builtin_amdgcn_cosf(u);

@@ -511,9 +511,9 @@ __device__ __forceinline__ float scatter(f3 p, f3 n, float smoothness, float4 m_
   // but no draw waits for the one before it (1.5 % off the chain of a wave that runs alone).
   const uint32_t s0 = rng;
   rng = pcg_jump(s0, 7);
-  float x = M::sqrt(M::neg2log(pcg_output_float(pcg_jump(s0, 2)))) * M::box_cos(pcg_output_float(pcg_jump(s0, 1)));
-  float y = M::sqrt(M::neg2log(pcg_output_float(pcg_jump(s0, 4)))) * M::box_cos(pcg_output_float(pcg_jump(s0, 3)));
-  float z = M::sqrt(M::neg2log(pcg_output_float(pcg_jump(s0, 6)))) * M::box_cos(pcg_output_float(pcg_jump(s0, 5)));
+  float x = M::sqrt(M::neg2log_bits(pcg_output_bits(pcg_jump(s0, 2)))) * M::box_cos_bits(pcg_output_bits(pcg_jump(s0, 1)));
+  float y = M::sqrt(M::neg2log_bits(pcg_output_bits(pcg_jump(s0, 4)))) * M::box_cos_bits(pcg_output_bits(pcg_jump(s0, 3)));
+  float z = M::sqrt(M::neg2log_bits(pcg_output_bits(pcg_jump(s0, 6)))) * M::box_cos_bits(pcg_output_bits(pcg_jump(s0, 5)));
   const float u_spec = pcg_output_float(rng);
   f3 rd = M::normalize(mk3(x, y, z));
   f3 diffuse = M::normalize(n + rd);         // (:202)
