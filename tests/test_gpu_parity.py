@@ -439,6 +439,35 @@ def test_caller_owned_accumulation_buffer_and_stream():
             assert np.max(np.abs(r.read_rgba8()[..., :3].astype(int) - want8.astype(int))) <= 1
 
 
+def test_two_kernel_launches_are_ordered_on_the_callers_stream():
+    """Launches of 32 or more samples per pixel run as two kernels, one of them on a stream the
+    context owns.  Work the caller puts on ITS stream right after rt_render must still see the
+    finished image, and the next render must see the previous one's."""
+    import torch
+    w, h = 320, 200
+    ubo = rt.make_ubo(w, h, 8, 12, sun_intensity=2.0)
+    sph = rt.default_scene()
+    ref1 = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL_NESTED, 0, 0, 4, 1)
+    ref2 = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL_NESTED, 0, 0, 12, 1)
+    dev = torch.device("cuda", 0)
+    mine = torch.cuda.Stream(device=dev)
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.stream(mine):
+        accum.zero_()
+        with rt.Renderer(w, h, stream=mine.cuda_stream, accum_buffer=accum.data_ptr()) as r:
+            r.set_params(ubo)
+            r.set_spheres(sph)
+            r.render(0, 4, 1)
+            snap1 = accum.clone()            # on the caller's stream, straight after the launch
+            r.render(4, 4, 1)
+            r.render(8, 4, 1)
+            snap2 = accum.clone()
+            mine.synchronize()
+            assert np.array_equal(snap1.cpu().numpy().view(np.uint32), _bits(ref1["accum"]))
+            assert np.array_equal(snap2.cpu().numpy().view(np.uint32), _bits(ref2["accum"]))
+            assert r.stats().rays == ref2["rays"]
+
+
 def test_linear_accumulation_resolve(oracle):
     w, h = 64, 40
     ubo = rt.make_ubo(w, h, 2, 6)
