@@ -99,8 +99,8 @@ struct rt_ctx {
   float *d_ior = nullptr;        // per sphere, > 0: dielectric (optional; null: none)
   bool have_ior = false;
 
-  uchar4 *d_texels = nullptr;    // albedo texture (optional)
-  float *d_tex_lut = nullptr;    // byte -> linear value
+  float4 *d_texels = nullptr;    // albedo texture (optional), decoded to linear rgb floats
+  float *d_tex_lut = nullptr;    // byte -> linear value (used while a texture is being bound)
   rt::Texture *d_tex = nullptr;  // device copy of the binding
   bool have_tex = false;
 
@@ -652,8 +652,7 @@ static int rt_set_texture_impl(rt_ctx *c, const rt_texture_desc *desc, const voi
   c->have_tex = false;
   if (!desc) return RT_OK;
   const size_t n = (size_t)desc->width * desc->height;
-  RT_HIP(hipMalloc(&c->d_texels, n * sizeof(uchar4)));
-  RT_HIP(hipMemcpy(c->d_texels, rgba8, n * sizeof(uchar4), hipMemcpyHostToDevice));
+  RT_HIP(hipMalloc(&c->d_texels, n * sizeof(float4)));
   if (!c->d_tex_lut) RT_HIP(hipMalloc(&c->d_tex_lut, 256 * sizeof(float)));
   float lut[256];
   for (int i = 0; i < 256; ++i) {
@@ -666,9 +665,18 @@ static int rt_set_texture_impl(rt_ctx *c, const rt_texture_desc *desc, const voi
     }
   }
   RT_HIP(hipMemcpy(c->d_tex_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+  {
+    // the bytes go up once and are decoded on the device; the staging copy is dropped again
+    uchar4 *d_bytes = nullptr;
+    RT_HIP(hipMalloc(&d_bytes, n * sizeof(uchar4)));
+    hipError_t e = hipMemcpy(d_bytes, rgba8, n * sizeof(uchar4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt::launch_decode_texels(d_bytes, c->d_tex_lut, c->d_texels, n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_bytes);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_set_texture: %s", hipGetErrorString(e));
+  }
   rt::Texture t{};
   t.texels = c->d_texels;
-  t.lut = c->d_tex_lut;
   t.width = desc->width;
   t.height = desc->height;
   t.fwidth = (float)desc->width;

@@ -67,8 +67,10 @@ __host__ __device__ inline uint32_t leaf_ref_count(int32_t ref) { return ((uint3
 
 // Albedo texture bound to a range of primitive ids (texels == null: none).
 struct Texture {
-  const uchar4 *texels;     // width * height, row 0 = v 0
-  const float *lut;         // 256 entries: texel byte -> linear value
+  // width * height texels, row 0 = v 0, decoded to linear rgb floats when the texture is bound
+  // (through the 256-entry byte -> linear table): a sample is then four independent 16-byte
+  // fetches instead of four texel words followed by twelve table look-ups that wait for them
+  const float4 *texels;
   uint32_t width, height;
   float fwidth, fheight;
   float scale_u, scale_v;

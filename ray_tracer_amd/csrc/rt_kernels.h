@@ -34,6 +34,8 @@ hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, c
 // and material arrays
 hipError_t launch_repack_spheres(const void *spheres64, uint32_t n, uint32_t n_geom, float4 *geom,
                                  float4 *material, hipStream_t stream);
+// texel bytes -> linear rgb floats through a 256-entry table (w = 0)
+hipError_t launch_decode_texels(const uchar4 *texels, const float *lut, float4 *out, size_t n, hipStream_t stream);
 // adds the kRaySlots spread counters up into *total and clears them
 hipError_t launch_fold_rays(unsigned long long *slots, unsigned long long *total, hipStream_t stream);
 // tile costs of the last launch -> heaviest-first launch order; clears the costs

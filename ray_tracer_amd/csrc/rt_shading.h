@@ -426,7 +426,8 @@ __device__ __forceinline__ void texture_coords(const Texture &T, f3 p, f3 n, flo
 
 // Bilinear sample, one unit of (u, v) = one repeat: the fractional part of the coordinate
 // picks the position, texel centres at half-integers, the two columns and rows wrap,
-// bytes become floats through the table, lerps are fma(weight, right - left, left).
+// bytes became floats through the table when the texture was bound, lerps are
+// fma(weight, right - left, left).
 __device__ __forceinline__ f3 texture_sample(const Texture &T, float u, float v) {
   const int W = (int)T.width, H = (int)T.height;
   float ur = u - __builtin_floorf(u), vr = v - __builtin_floorf(v);
@@ -439,18 +440,20 @@ __device__ __forceinline__ f3 texture_sample(const Texture &T, float u, float v)
   if (ix0 >= W) ix0 = W - 1;
   if (iy0 >= H) iy0 = H - 1;
   const int ix1 = ix0 + 1 == W ? 0 : ix0 + 1, iy1 = iy0 + 1 == H ? 0 : iy0 + 1;
-  // texels as packed words; one channel at a time keeps few values live next to the path state
-  const uint32_t *texels = (const uint32_t *)T.texels;
-  const uint32_t c00 = scene_u32(texels, (size_t)iy0 * W + ix0), c10 = scene_u32(texels, (size_t)iy0 * W + ix1);
-  const uint32_t c01 = scene_u32(texels, (size_t)iy1 * W + ix0), c11 = scene_u32(texels, (size_t)iy1 * W + ix1);
+  const float4 c00 = scene_f4(T.texels, (size_t)iy0 * W + ix0), c10 = scene_f4(T.texels, (size_t)iy0 * W + ix1);
+  const float4 c01 = scene_f4(T.texels, (size_t)iy1 * W + ix0), c11 = scene_f4(T.texels, (size_t)iy1 * W + ix1);
   float out[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const uint32_t sh = 8u * (uint32_t)k;
-    const float fa = scene_f32(T.lut, (c00 >> sh) & 255u), fb = scene_f32(T.lut, (c10 >> sh) & 255u);
-    const float fc = scene_f32(T.lut, (c01 >> sh) & 255u), fd = scene_f32(T.lut, (c11 >> sh) & 255u);
-    const float top = __builtin_fmaf(fx, fb - fa, fa), bot = __builtin_fmaf(fx, fd - fc, fc);
-    out[k] = __builtin_fmaf(fy, bot - top, top);
+  {
+    const float top = __builtin_fmaf(fx, c10.x - c00.x, c00.x), bot = __builtin_fmaf(fx, c11.x - c01.x, c01.x);
+    out[0] = __builtin_fmaf(fy, bot - top, top);
+  }
+  {
+    const float top = __builtin_fmaf(fx, c10.y - c00.y, c00.y), bot = __builtin_fmaf(fx, c11.y - c01.y, c01.y);
+    out[1] = __builtin_fmaf(fy, bot - top, top);
+  }
+  {
+    const float top = __builtin_fmaf(fx, c10.z - c00.z, c00.z), bot = __builtin_fmaf(fx, c11.z - c01.z, c01.z);
+    out[2] = __builtin_fmaf(fy, bot - top, top);
   }
   return mk3(out[0], out[1], out[2]);
 }

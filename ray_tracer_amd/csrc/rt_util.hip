@@ -150,6 +150,25 @@ hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, c
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_decode_texels(const uchar4 *__restrict__ texels, const float *__restrict__ lut,
+                                                       float4 *__restrict__ out, size_t n) {
+  __shared__ float table[256];
+  table[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+    const uchar4 t = texels[i];
+    out[i] = make_float4(table[t.x], table[t.y], table[t.z], 0.0f);
+  }
+}
+
+hipError_t launch_decode_texels(const uchar4 *texels, const float *lut, float4 *out, size_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const size_t blocks = (n + 255u) / 256u;
+  hipLaunchKernelGGL(k_decode_texels, dim3((unsigned)(blocks < 8192u ? blocks : 8192u)), dim3(256), 0, stream, texels,
+                     lut, out, n);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(1024) void k_fold_rays(unsigned long long *__restrict__ slots,
                                                     unsigned long long *__restrict__ total) {
   static_assert(kRaySlots == 1024, "one thread per counter");
