@@ -127,7 +127,9 @@ int rt_set_mesh_device(rt_ctx *ctx, const float *d_vertices, uint32_t n_vertices
  *   mapping   RT_TEX_MAP_PLANAR_XZ: (u, v) = (point.x * scale_u, point.z * scale_v)
  *             RT_TEX_MAP_OCTAHEDRAL: the unit normal folded onto a square (spheres),
  *             (u, v) = (a * scale_u, b * scale_v) with a, b in [0, 1]
- * One unit of u or v is one repeat of the image.  desc == NULL removes the texture. */
+ * One unit of u or v is one repeat of the image.  desc == NULL removes the texture.
+ * The texels are kept on the device decoded to linear floats, 16 bytes each (a 32768 x 32768
+ * image takes 16 GiB; RT_ERR_DEVICE if that cannot be allocated). */
 #define RT_TEX_SRGB 1u
 #define RT_TEX_MAP_PLANAR_XZ 0u
 #define RT_TEX_MAP_OCTAHEDRAL 1u
