@@ -24,7 +24,7 @@
 #define RT_REGEN_END_BATCH 24  // ended paths a wave gathers before it runs the path-end code (8 and 24 within 1 % once hits are gathered too)
 #endif
 #ifndef RT_SCHED_WAVES
-#define RT_SCHED_WAVES 6  // waves per SIMD the untextured fast k_mega_sched is compiled for (80 VGPR; 3840x2160, 10k spheres / terrain: 5 waves 5.42 / 14.65 ms, 6: 5.35 / 14.52, 7: 5.37 / 14.89)
+#define RT_SCHED_WAVES 6  // waves per SIMD the untextured fast k_mega_sched is compiled for (80 VGPR; uncapped it wants 83-87 and runs 5: no scratch instead of 20-36 bytes per lane, 10k spheres 1920x1080 2.11 -> 2.02 ms, but the 3840x2160 batch 110.3 -> 115.4 ms; terrain the same)
 #endif
 #ifndef RT_XCD_TILES
 #define RT_XCD_TILES 1  // k_mega_sched: the four waves of a tile on one XCD (0: consecutive blocks, i.e. four XCDs)
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
   // launch and ran on alone for its last quarter.
   uint32_t steps = 0;
   while (true) {
-    ++steps;
+    steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)steps) + 1u;  // (wave-uniform: kept in a scalar register)
     const bool want_inner = active && Q.node >= 0;
     const bool want_shade = active && Q.node == kSearchOver;
     const bool want_leaf = active && !want_inner && !want_shade;
