@@ -229,7 +229,7 @@ def main() -> None:
     # own: the LBVH rebuild of frame i+1 (sixty small kernels and two host read-backs) then runs
     # beside the trace of frame i instead of between two traces.  Every frame is still rebuilt
     # and traced inside the timed region.
-    pipelined = world == 1 and wl["scene"] == "terrain" and args.images_in_flight != 1
+    pipelined = world == 1 and ((wl["scene"] == "terrain" and args.images_in_flight != 1) or args.images_in_flight > 1)
     n_buf = args.images_in_flight if args.images_in_flight > 0 else (2 if world > 1 or pipelined else 1)
     stream = torch.cuda.current_stream(dev)
     streams = [torch.cuda.Stream(device=dev) if pipelined else stream for _ in range(n_buf)]
