@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Randomised strict-mode parity runs: HIP kernels (through the C ABI) against the CPU oracle.
+
+    python tests/fuzz_parity.py [cases] [seed]
+
+Not collected by pytest (a long-running hunt for rare mismatches, run by hand on a GPU box).
+Every case draws a scene (1 to 60 spheres of random size and material, some of them glass; sometimes
+a small random triangle mesh, sometimes a texture), a camera, an image size that is not a multiple
+of the tile, sample / bounce / frame counts, a kernel organisation and a search (brute force or
+LBVH), renders it in strict-math mode, and demands the oracle's accumulation image, 8-bit image,
+primary ids and segment count bit for bit.  The first mismatch stops the run with the case's seed.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _oracle as oracle  # noqa: E402
+import ray_tracer_amd as rt  # noqa: E402
+
+
+def random_case(rng):
+    w = int(rng.integers(17, 150))
+    h = int(rng.integers(17, 110))
+    spp = int(rng.choice([1, 2, 3, 5, 8]))
+    bounces = int(rng.choice([1, 2, 4, 7, 12]))
+    frames = int(rng.choice([1, 1, 2, 4, 8]))
+    if spp * frames >= 32 and rng.random() < 0.5:
+        frames = 4   # keep most cases cheap, some above the two-kernel threshold
+    ubo = rt.make_ubo(w, h, spp, bounces, pitch=float(rng.uniform(-0.5, 0.5)), yaw=float(rng.uniform(-3.1, 3.1)),
+                      diverge=float(rng.choice([0.0, 1.0, 3.0])), defocus=float(rng.choice([0.0, 0.0, 2.0])),
+                      sun_intensity=float(rng.choice([0.0, 2.0])))
+    n = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 60]))
+    base = rt.default_scene()
+    sph = np.zeros((n, 16), dtype=np.float32)
+    for i in range(n):
+        s = base[i % 3].copy()
+        if i == 0 and rng.random() < 0.7:
+            s[0:4] = [0.0, -1000.0 - rng.random(), 0.0, 1000.0]          # a ground sphere
+        else:
+            s[0:3] = rng.uniform(-6.0, 6.0, 3) + np.array([0.0, 1.0, -8.0])
+            s[3] = rng.uniform(0.2, 2.0)
+        s[4:7] = rng.uniform(0.1, 1.0, 3)                                  # colour
+        s[7] = float(rng.choice([0.0, 0.5, 1.0]))                          # smoothness
+        s[8:11] = rng.uniform(0.0, 1.0, 3)                                 # emission colour
+        s[11] = float(rng.choice([0.0, 0.0, 0.0, 3.0]))                    # emission strength
+        s[12:15] = rng.uniform(0.5, 1.0, 3)                                # specular colour
+        s[15] = float(rng.choice([0.0, 0.2, 1.0]))                         # specular probability
+        sph[i] = s
+    ior = None
+    if rng.random() < 0.4:
+        ior = np.where(rng.random(n) < 0.4, np.float32(1.5), np.float32(0.0)).astype(np.float32)
+        ior[0] = 0.0
+    mesh = None
+    if rng.random() < 0.35:
+        nv = int(rng.integers(3, 40))
+        v = (rng.uniform(-5.0, 5.0, (nv, 3)) + np.array([0.0, 1.0, -8.0])).astype(np.float32)
+        t = rng.integers(0, nv, (int(rng.integers(1, 60)), 3)).astype(np.uint32)
+        mesh = (v, t, rt.matte(0.6, 0.5, 0.4, smoothness=float(rng.choice([0.0, 0.8])),
+                               specular_probability=float(rng.choice([0.0, 0.3]))))
+    tex = None
+    if rng.random() < 0.3:
+        tw, th = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+        tex = dict(rgba8=rng.integers(0, 256, (th, tw, 4), dtype=np.uint8), first_prim=0,
+                   n_prims=int(rng.integers(1, n + 1)), mapping=int(rng.integers(0, 2)),
+                   scale=(float(rng.uniform(0.05, 2.0)), float(rng.uniform(0.05, 2.0))), srgb=bool(rng.integers(0, 2)))
+    mode = int(rng.choice([rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT]))
+    search = int(rng.choice([rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH, 0]))
+    first = int(rng.integers(0, 1000))
+    calls = int(rng.choice([1, 1, 2, 3]))   # several launches: the later ones run tile-ordered forms
+    return dict(w=w, h=h, ubo=ubo, sph=sph, ior=ior, mesh=mesh, tex=tex, mode=mode, search=search,
+                first=first, frames=frames, calls=calls)
+
+
+def run_case(c):
+    flags = rt.FLAG_STRICT_MATH | c["search"]
+    want = None
+    acc = img = None
+    for k in range(c["calls"]):
+        want = oracle.render(c["ubo"], c["sph"], c["w"], c["h"], first_frame=c["first"] + k * c["frames"],
+                             n_frames=c["frames"], mesh=c["mesh"], texture=c["tex"], ior=c["ior"], accum=acc, rgba8=img)
+        acc, img = want["accum"], want["rgba8"]
+    rays_want = 0
+    with rt.Renderer(c["w"], c["h"], mode=c["mode"], flags=flags) as r:
+        r.set_params(c["ubo"])
+        r.set_spheres(c["sph"])
+        if c["ior"] is not None:
+            r.set_dielectric(c["ior"])
+        if c["mesh"] is not None:
+            r.set_mesh(*c["mesh"])
+        if c["tex"] is not None:
+            t = c["tex"]
+            r.set_texture(t["rgba8"], t["first_prim"], t["n_prims"], t["mapping"], t["scale"], t["srgb"])
+        for k in range(c["calls"]):
+            r.render(c["first"] + k * c["frames"], c["frames"], 1)
+        r.sync()
+        got = dict(accum=r.read_accum(), rgba8=r.read_rgba8(), ids=r.read_primary_ids(), rays=int(r.stats().rays))
+    # the oracle counts segments per call; the library since the context was created
+    for k in range(c["calls"]):
+        rays_want += int(oracle.render(c["ubo"], c["sph"], c["w"], c["h"], first_frame=c["first"] + k * c["frames"],
+                                       n_frames=c["frames"], mesh=c["mesh"], texture=c["tex"], ior=c["ior"])["rays"])
+    a = np.asarray(got["accum"], dtype=np.float32).view(np.uint32)
+    b = np.asarray(want["accum"], dtype=np.float32).view(np.uint32)
+    nan_ok = np.isnan(got["accum"]) & np.isnan(want["accum"])   # log(0) draws: NaN on both sides, payload aside
+    problems = []
+    if not np.array_equal(np.where(nan_ok, 0, a), np.where(nan_ok, 0, b)):
+        problems.append(f"accum differs in {int(((a != b) & ~nan_ok).any(axis=-1).sum())} pixels")
+    if not np.array_equal(got["rgba8"], want["rgba8"]):
+        problems.append(f"rgba8 differs in {int((got['rgba8'] != want['rgba8']).any(axis=-1).sum())} pixels")
+    if not np.array_equal(got["ids"], want["ids"]):
+        problems.append(f"ids differ in {int((got['ids'] != want['ids']).sum())} pixels")
+    if got["rays"] != rays_want:
+        problems.append(f"rays {got['rays']} != {rays_want}")
+    return problems
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    for i in range(cases):
+        rng = np.random.default_rng([seed, i])
+        c = random_case(rng)
+        problems = run_case(c)
+        tag = (f"case {i} (seed {seed}): {c['w']}x{c['h']} spheres {c['sph'].shape[0]} mode {c['mode']} search {c['search']} "
+               f"spp {int(c['ubo'][40])} bounces {int(c['ubo'][41])} frames {c['frames']} x {c['calls']} "
+               f"glass {c['ior'] is not None} mesh {c['mesh'] is not None} tex {c['tex'] is not None}")
+        if problems:
+            print("MISMATCH", tag, problems, flush=True)
+            return 1
+        if i % 20 == 0:
+            print("ok", tag, flush=True)
+    print(f"{cases} cases, no mismatch", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
