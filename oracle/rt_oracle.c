@@ -603,6 +603,16 @@ static inline v3 dielectric_scatter(v3 d, v3 n, float ior, int exiting, uint32_t
   return v_fma(nl, par, perp);
 }
 
+/* Debugging aid for the tests: while a log is set (rto_debug_log), every closest-hit search of
+ * trace_path appends 8 floats -- origin, direction, hit index (-1: none), distance.  Meant for a
+ * one-pixel list rendered on one thread. */
+static float *g_debug_log = NULL;
+static uint32_t g_debug_cap = 0, g_debug_n = 0;
+void rto_debug_log(float *records8, uint32_t max_records) {
+  g_debug_log = records8; g_debug_cap = max_records; g_debug_n = 0;
+}
+uint32_t rto_debug_log_count(void) { return g_debug_n; }
+
 /* trace, ray_tracing.comp:192-222; first_id receives the first segment's hit index */
 static inline v3 trace_path(const frame_ctx *fc, v3 o, v3 d, uint32_t *rng, int *first_id,
                             uint64_t *rays) {
@@ -611,6 +621,11 @@ static inline v3 trace_path(const frame_ctx *fc, v3 o, v3 d, uint32_t *rng, int 
   for (int i = 0; (float)i < fc->max_bounce; ++i) {
     hit_t h = closest_hit(fc, o, d, skip);
     ++*rays;
+    if (g_debug_log && g_debug_n < g_debug_cap) {
+      float *r = g_debug_log + 8u * g_debug_n++;
+      r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+      r[6] = h.hit ? (float)h.index : -1.0f; r[7] = h.dst;
+    }
     if (i == 0 && first_id) *first_id = h.hit ? h.index : -1;
     if (h.hit) {
       /* colour, emission, specular: the sphere's own, or the mesh's one material */

@@ -167,6 +167,12 @@ typedef struct rto_job {
 } rto_job;
 int rto_render_job(const rto_job *job);
 
+/* Debugging aid: while records8 is non-NULL every closest-hit search of a render appends 8 floats
+ * (origin, direction, hit index or -1, distance) up to max_records; for a one-pixel list on one
+ * thread.  rto_debug_log(NULL, 0) switches it off; rto_debug_log_count() = records written. */
+void rto_debug_log(float *records8, uint32_t max_records);
+uint32_t rto_debug_log_count(void);
+
 /* one bilinear sample of the texture at (u, v), for unit tests of the sampling rule */
 void rto_texture_sample(const rto_texture *texture, float u, float v, float out_rgb[3]);
 

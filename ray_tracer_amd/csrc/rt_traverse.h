@@ -21,9 +21,16 @@ constexpr int kBlockThreads = 256;
 // instruction per plane instead of two.  Against (plane - o) * (1/d) this adds an absolute
 // error of half an ulp of o/d, i.e. at most 6e-8 |o| in space, which is 1.5 % of the
 // smallest margin the leaf boxes carry (4e-6 D for triangles, with |o| <= D; the sphere
-// margin 4.8e-7 D^2 / r is larger still).  A zero direction component makes a plane term
-// NaN; min/max then return the other operand, so that slab only stops constraining the
-// test (never a false miss).
+// margin 4.8e-7 D^2 / r is larger still).
+// 1/d is kept finite (slab_rcp): with an infinite one, a zero direction component turns the plane
+// terms of a box that straddles the coordinate's origin into -inf and NaN (plane * inf - o * inf),
+// the slab's far distance into -inf, and the box -- typically the root -- into a false miss.
+// Clamped to +-2^64 the component behaves like a direction of 2^-64: the slab of a box the ray
+// runs inside of comes out as (-huge, +huge) and stops constraining the test, and a box the ray
+// runs beside is missed, as it should be.
+__device__ __forceinline__ float slab_rcp(float d) {
+  return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d), -0x1p64f, 0x1p64f);
+}
 __device__ __forceinline__ float slab_entry(const float lo[3], const float hi[3], f3 oi, f3 inv_d,
                                             float limit) {
   float x0 = __builtin_fmaf(lo[0], inv_d.x, -oi.x), x1 = __builtin_fmaf(hi[0], inv_d.x, -oi.x);
@@ -94,7 +101,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
   const float a = dot(d, d);
   Closest<APPROX> C;
   C.reset(a);
-  const f3 inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
+  const f3 inv_d = mk3(slab_rcp(d.x), slab_rcp(d.y),
                        __builtin_amdgcn_rcpf(d.z));
   const f3 oi = mk3(o.x * inv_d.x, o.y * inv_d.y, o.z * inv_d.z);
   large_candidates<DIEL>(S, o, d, a, skip, C);
@@ -190,7 +197,7 @@ template <bool DIEL = false, bool APPROX>
 __device__ __forceinline__ void search_begin(const Scene &S, f3 o, f3 d, int skip, Search<APPROX> &Q) {
   Q.a = dot(d, d);
   Q.best.reset(Q.a);
-  Q.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+  Q.inv_d = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
   Q.oi = mk3(o.x * Q.inv_d.x, o.y * Q.inv_d.y, o.z * Q.inv_d.z);
   large_candidates<DIEL>(S, o, d, Q.a, skip, Q.best);
   Q.sp = 0;

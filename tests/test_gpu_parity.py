@@ -369,6 +369,31 @@ def test_lbvh_equal_distance_ties_pick_lowest_index(oracle):
     assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
 
 
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT])
+def test_lbvh_rays_with_a_zero_direction_component(oracle, mode):
+    """With divergence off and an unrotated camera the pixels of column w/2 and of row h/2 look
+    along directions whose x (y) component is exactly zero, and the defocus jitter moves their
+    origins off x = 0 (y = 0).  The slab test divides by the direction: a box that straddles the
+    origin of that coordinate -- the root -- must not turn into a miss for such a ray.  (Found by
+    tests/fuzz_parity.py on a bounce ray; here the same kind of ray is a primary ray.)"""
+    w, h = 64, 48
+    ubo = rt.make_ubo(w, h, 4, 4, diverge=0.0, defocus=40.0)
+    rng = np.random.default_rng(5)
+    sph = np.repeat(rt.default_scene()[:1], 24, axis=0).copy()
+    sph[:, 0:3] = rng.uniform(-3.0, 3.0, (24, 3)) + np.array([0.0, 0.0, -7.0])
+    sph[:, 3] = rng.uniform(0.3, 0.9, 24)
+    want = oracle.render(ubo, sph, w, h)
+    assert (want["ids"][:, w // 2] >= 0).any() and (want["ids"][h // 2, :] >= 0).any()
+    brute = gpu_render(ubo, sph, w, h, mode, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BRUTE)
+    got = gpu_render(ubo, sph, w, h, mode, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+    assert np.array_equal(brute["ids"], want["ids"])
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+    fast = gpu_render(ubo, sph, w, h, mode, rt.FLAG_FORCE_BVH)
+    assert np.array_equal(fast["ids"][:, w // 2], want["ids"][:, w // 2])
+
+
 def test_lbvh_equals_brute_force_on_gpu_at_scale():
     """10k spheres, fast math: the LBVH and the brute-force kernels trace identical paths."""
     w, h = 640, 360
