@@ -105,6 +105,8 @@ int rt_set_spheres(rt_ctx *ctx, const void *spheres64, uint32_t count);
  * with the spheres.  vertices = n_vertices * xyz (12-byte stride), indices = 3 per
  * triangle.  Primitive ids of triangles follow the spheres: n_spheres + triangle index.
  * Both faces are hit; the shading normal is the geometric normal turned against the ray.
+ * A triangle without area (a repeated vertex, collinear vertices whose edge cross product is
+ * exactly zero) keeps its id but is never hit.
  * n_triangles = 0 removes the mesh.  Rebuilds the acceleration structure. */
 int rt_set_mesh(rt_ctx *ctx, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
                 uint32_t n_triangles, const rt_material *material);

@@ -410,7 +410,9 @@ static inline v3 v_cross(v3 a, v3 b) {
  *   tv = o-v0, un = tv.p, q = tv x e1, vn = d.q, tn = e2.q
  *   with s = sign(det): s*un >= 0, s*vn >= 0, s*(un+vn) <= s*det, s*tn >= 0   else miss
  *   dst = tn / det;  point = o + d*dst;  normal = normalize(e1 x e2), turned against d
- * Both faces are hit. */
+ * Both faces are hit.  A triangle without area -- e1 x e2 == (0, 0, 0) as computed by v_cross, which
+ * covers two equal vertices and collinear lattice points -- is never hit: the sign tests above
+ * would otherwise decide on rounding residue (closest_hit leaves such triangles out). */
 static inline hit_t ray_triangle(v3 o, v3 d, v3 v0, v3 v1, v3 v2) {
   hit_t h;
   h.hit = 0; h.dst = 0.0f; h.point = V3(0, 0, 0); h.normal = V3(0, 0, 0); h.index = -1;
@@ -459,6 +461,11 @@ static inline hit_t closest_hit(const frame_ctx *fc, v3 o, v3 d, int skip) {
       const float *a = m->vertices + 3u * m->indices[3u * t + 0];
       const float *b = m->vertices + 3u * m->indices[3u * t + 1];
       const float *c = m->vertices + 3u * m->indices[3u * t + 2];
+      {
+        v3 va = V3(a[0], a[1], a[2]);
+        v3 n = v_cross(v_sub(V3(b[0], b[1], b[2]), va), v_sub(V3(c[0], c[1], c[2]), va));
+        if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) continue;   /* no area: never hit */
+      }
       hit_t h = ray_triangle(o, d, V3(a[0], a[1], a[2]), V3(b[0], b[1], b[2]), V3(c[0], c[1], c[2]));
       if (h.hit && h.dst < best.dst) { best = h; best.index = id; }
     }

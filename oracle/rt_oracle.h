@@ -103,7 +103,7 @@ int rto_render(const void *ubo272, const void *spheres64, uint32_t n_spheres,
 /* Triangle mesh (EXTENSION: the reference traces spheres only; BASELINE.json asks for
  * triangles).  One material for the whole mesh.  Primitive ids of triangles follow the
  * spheres: n_spheres + triangle index.  Intersection rule: see ray_triangle() in
- * rt_oracle.c. */
+ * rt_oracle.c; a triangle without area (e1 x e2 == 0) is never hit. */
 typedef struct rto_mesh {
   const float *vertices;      /* xyz, 12-byte stride */
   uint32_t n_vertices;

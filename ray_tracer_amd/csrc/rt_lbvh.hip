@@ -124,7 +124,17 @@ __global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restric
         const float far = fmaxf(fabsf(c[k] - bp.blo[k]), fabsf(c[k] - bp.bhi[k])) + (hi[k] - lo[k]);
         d2 += far * far;
       }
-      const float m = 4.0e-6f * sqrtf(d2) + 1e-30f;
+      // ... and by more at a corner with a flat angle: the barycentric tests divide rounding
+      // residue by |e1 x e2|, so the margin grows with |e1| |e2| / |e1 x e2| (1 for a right angle
+      // at the first vertex; capped, which makes the box of a needle cover the scene)
+      const float e1[3] = {b.x - a.x, b.y - a.y, b.z - a.z}, e2[3] = {cc.x - a.x, cc.y - a.y, cc.z - a.z};
+      const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2],
+                  cz = e1[0] * e2[1] - e1[1] * e2[0];
+      const float l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+      const float area2 = cx * cx + cy * cy + cz * cz;
+      float aspect = area2 > 0.f ? sqrtf(l1 * l2 / area2) : 1.f;   // (no area at all: never hit, see k_expand_triangles)
+      aspect = fminf(fmaxf(aspect, 1.f), 1048576.f);
+      const float m = 4.0e-6f * sqrtf(d2) * aspect + 1e-30f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         lo[k] -= m;

@@ -74,6 +74,12 @@ __device__ __forceinline__ uint32_t ordered_bits(float f) {
 //   report[1..3]   minimum x, y, z over the vertices the triangles use (ordered bits)
 //   report[4..6]   maximum
 // A bad index reads vertex 0 instead, so the launch itself is always in bounds.
+// A triangle without area -- e1 x e2 == (0, 0, 0), each component as fma(a, b, -(c * d)): two equal
+// vertices, collinear lattice points -- is never hit (the rule of the triangle test: its sign
+// tests would decide on rounding residue, and would do so for rays nowhere near it, which no
+// tree search can reproduce).  It is stored with all three corners on its first vertex:
+// both edge vectors are then exactly zero, the determinant of the test is exactly zero, and the
+// test rejects it without an extra branch.
 __global__ __launch_bounds__(256) void k_expand_triangles(const float *__restrict__ vertices,
                                                           uint32_t n_vertices,
                                                           const uint32_t *__restrict__ indices,
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256) void k_expand_triangles(const float *__restric
   float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   uint32_t bad = 0xffffffffu;
   for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tris; t += gridDim.x * 256u) {
+    float c[3][3];
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
       uint32_t idx = indices[3u * t + v];
@@ -93,10 +100,19 @@ __global__ __launch_bounds__(256) void k_expand_triangles(const float *__restric
         idx = 0;
       }
       const float *p = vertices + 3u * (size_t)idx;
-      const float x = p[0], y = p[1], z = p[2];
-      tri[3u * t + v] = make_float4(x, y, z, 0.f);
-      mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
-      mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+      c[v][0] = p[0]; c[v][1] = p[1]; c[v][2] = p[2];
+      mn[0] = fminf(mn[0], c[v][0]); mn[1] = fminf(mn[1], c[v][1]); mn[2] = fminf(mn[2], c[v][2]);
+      mx[0] = fmaxf(mx[0], c[v][0]); mx[1] = fmaxf(mx[1], c[v][1]); mx[2] = fmaxf(mx[2], c[v][2]);
+    }
+    const float e1[3] = {c[1][0] - c[0][0], c[1][1] - c[0][1], c[1][2] - c[0][2]};
+    const float e2[3] = {c[2][0] - c[0][0], c[2][1] - c[0][1], c[2][2] - c[0][2]};
+    const float nx = __builtin_fmaf(e1[1], e2[2], -(e1[2] * e2[1])), ny = __builtin_fmaf(e1[2], e2[0], -(e1[0] * e2[2])),
+                nz = __builtin_fmaf(e1[0], e2[1], -(e1[1] * e2[0]));
+    const bool flat = nx == 0.0f && ny == 0.0f && nz == 0.0f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int s = flat ? 0 : v;
+      tri[3u * t + v] = make_float4(c[s][0], c[s][1], c[s][2], 0.f);
     }
   }
   // wave, then block, then one atomic per block and value

@@ -32,7 +32,13 @@ def random_case(rng):
     ubo = rt.make_ubo(w, h, spp, bounces, pitch=float(rng.uniform(-0.5, 0.5)), yaw=float(rng.uniform(-3.1, 3.1)),
                       diverge=float(rng.choice([0.0, 1.0, 3.0])), defocus=float(rng.choice([0.0, 0.0, 2.0])),
                       sun_intensity=float(rng.choice([0.0, 2.0])))
-    n = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 60]))
+    n = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 60, 150]))
+    # a third of the cases sit on a lattice (integer centres, radii and vertices, no camera rotation,
+    # no divergence): exact ties, rays along axes and through edges and vertices
+    lattice = rng.random() < 0.33
+    if lattice:
+        ubo = rt.make_ubo(w, h, spp, bounces, diverge=0.0, defocus=float(rng.choice([0.0, 0.0, 16.0])),
+                          sun_intensity=float(rng.choice([0.0, 2.0])))
     base = rt.default_scene()
     sph = np.zeros((n, 16), dtype=np.float32)
     for i in range(n):
@@ -42,6 +48,9 @@ def random_case(rng):
         else:
             s[0:3] = rng.uniform(-6.0, 6.0, 3) + np.array([0.0, 1.0, -8.0])
             s[3] = rng.uniform(0.2, 2.0)
+            if lattice:
+                s[0:3] = np.rint(s[0:3])
+                s[3] = float(rng.choice([0.5, 1.0, 1.0, 2.0]))
         s[4:7] = rng.uniform(0.1, 1.0, 3)                                  # colour
         s[7] = float(rng.choice([0.0, 0.5, 1.0]))                          # smoothness
         s[8:11] = rng.uniform(0.0, 1.0, 3)                                 # emission colour
@@ -57,6 +66,8 @@ def random_case(rng):
     if rng.random() < 0.35:
         nv = int(rng.integers(3, 40))
         v = (rng.uniform(-5.0, 5.0, (nv, 3)) + np.array([0.0, 1.0, -8.0])).astype(np.float32)
+        if lattice:
+            v = np.rint(v).astype(np.float32)
         t = rng.integers(0, nv, (int(rng.integers(1, 60)), 3)).astype(np.uint32)
         mesh = (v, t, rt.matte(0.6, 0.5, 0.4, smoothness=float(rng.choice([0.0, 0.8])),
                                specular_probability=float(rng.choice([0.0, 0.3]))))
@@ -70,17 +81,20 @@ def random_case(rng):
     search = int(rng.choice([rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH, 0]))
     first = int(rng.integers(0, 1000))
     calls = int(rng.choice([1, 1, 2, 3]))   # several launches: the later ones run tile-ordered forms
+    linear = bool(rng.random() < 0.2)
     return dict(w=w, h=h, ubo=ubo, sph=sph, ior=ior, mesh=mesh, tex=tex, mode=mode, search=search,
-                first=first, frames=frames, calls=calls)
+                first=first, frames=frames, calls=calls, linear=linear, lattice=lattice)
 
 
 def run_case(c):
-    flags = rt.FLAG_STRICT_MATH | c["search"]
+    flags = rt.FLAG_STRICT_MATH | c["search"] | (rt.FLAG_ACCUM_LINEAR if c.get("linear") else 0)
+    amode = oracle.ACCUM_LINEAR if c.get("linear") else oracle.ACCUM_GAMMA
     want = None
     acc = img = None
     for k in range(c["calls"]):
         want = oracle.render(c["ubo"], c["sph"], c["w"], c["h"], first_frame=c["first"] + k * c["frames"],
-                             n_frames=c["frames"], mesh=c["mesh"], texture=c["tex"], ior=c["ior"], accum=acc, rgba8=img)
+                             n_frames=c["frames"], mesh=c["mesh"], texture=c["tex"], ior=c["ior"], accum=acc, rgba8=img,
+                             accum_mode=amode)
         acc, img = want["accum"], want["rgba8"]
     rays_want = 0
     with rt.Renderer(c["w"], c["h"], mode=c["mode"], flags=flags) as r:
@@ -125,7 +139,8 @@ def main():
         problems = run_case(c)
         tag = (f"case {i} (seed {seed}): {c['w']}x{c['h']} spheres {c['sph'].shape[0]} mode {c['mode']} search {c['search']} "
                f"spp {int(c['ubo'][40])} bounces {int(c['ubo'][41])} frames {c['frames']} x {c['calls']} "
-               f"glass {c['ior'] is not None} mesh {c['mesh'] is not None} tex {c['tex'] is not None}")
+               f"glass {c['ior'] is not None} mesh {c['mesh'] is not None} tex {c['tex'] is not None} "
+               f"lattice {c['lattice']} linear {c['linear']}")
         if problems:
             print("MISMATCH", tag, problems, flush=True)
             return 1

@@ -555,6 +555,33 @@ def test_mesh_and_spheres_bit_exact(oracle, mode, accel):
     assert np.array_equal(got["rgba8"], want["rgba8"])
 
 
+@pytest.mark.parametrize("accel", [rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH])
+def test_triangles_without_area_are_never_hit(oracle, accel):
+    """OBJ files carry faces with a repeated vertex or three collinear ones.  The triangle test's sign
+    checks would decide on rounding residue for them -- and report 'hits' at distance 0 for rays that
+    point nowhere near, which a tree search cannot reproduce -- so the rule is that a triangle whose
+    edge cross product is exactly zero is never hit.  (Found by tests/fuzz_parity.py.)"""
+    w, h = 62, 108
+    ubo = rt.make_ubo(w, h, 2, 3, diverge=0.0)
+    sph = rt.default_scene()[:1].copy()
+    sph[0, :4] = (3, 4, -8, 1)
+    v = np.array([[5, -4, -12], [3, -1, -5], [-4, 2, -9], [0, 0, -6], [2, 2, -8], [4, 4, -10],
+                  [-3, -3, -7], [3, -3, -7], [0, 3, -7]], dtype=np.float32)
+    t = np.array([[0, 1, 1],      # a repeated vertex
+                  [2, 2, 2],      # a point
+                  [3, 4, 5],      # collinear lattice points
+                  [6, 7, 8]],     # a proper triangle in front of the camera
+                 dtype=np.uint32)
+    mat = rt.matte(0.7, 0.6, 0.4, smoothness=0.5, specular_probability=0.5)
+    want = oracle.render(ubo, sph, w, h, 90, 1, 1, mesh=(v, t, mat))
+    assert set(np.unique(want["ids"])) <= {-1, 0, 4}      # only the sphere and the proper triangle
+    assert (want["ids"] == 4).sum() > 100
+    got = gpu_render_mesh(ubo, sph, (v, t, mat), w, h, rt.MODE_MEGAKERNEL_NESTED, rt.FLAG_STRICT_MATH | accel, 90, 1, 1)
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+
+
 def test_mesh_only_scene_and_removal(oracle):
     w, h = 96, 64
     ubo = rt.make_ubo(w, h, 1, 4)

@@ -465,3 +465,16 @@ def test_pixel_list_equals_the_whole_image(oracle):
     every = oracle.render(ubo, sph, w, h, 1, 2, 3, pixels=np.arange(w * h, dtype=np.uint32))
     assert every["rays"] == full["rays"]
     assert np.array_equal(every["accum"].reshape(h, w, 4), full["accum"])
+
+
+def test_triangle_without_area_is_never_hit(oracle):
+    """Repeated vertices and collinear lattice points: e1 x e2 == 0 exactly, the triangle is left out."""
+    w, h = 32, 32
+    ubo = oracle.default_ubo()
+    ubo[40], ubo[41], ubo[66], ubo[67] = 1, 1, 0, 0
+    none = np.zeros((0, 16), np.float32)
+    v = np.array([[5, -4, -12], [3, -1, -5], [0, 0, -6], [2, 2, -8], [4, 4, -10]], dtype=np.float32)
+    mat = np.array([1, 1, 1, 0, 0, 0, 0, 0, 1, 1, 1, 0], dtype=np.float32)
+    for tri in ([0, 1, 1], [1, 1, 1], [2, 3, 4]):
+        r = oracle.render(ubo, none, w, h, mesh=(v, np.array([tri], dtype=np.uint32), mat))
+        assert (r["ids"] == -1).all()
