@@ -409,6 +409,7 @@ static inline v3 v_cross(v3 a, v3 b) {
  *   e1 = v1-v0, e2 = v2-v0, p = d x e2, det = e1.p          (det == 0: parallel, miss)
  *   tv = o-v0, un = tv.p, q = tv x e1, vn = d.q, tn = e2.q
  *   with s = sign(det): s*un >= 0, s*vn >= 0, s*(un+vn) <= s*det, s*tn >= 0   else miss
+ *   det*det > 2^-40 (e1.e1)(p.p)   else miss (the ray runs in the triangle's plane)
  *   dst = tn / det;  point = o + d*dst;  normal = normalize(e1 x e2), turned against d
  * Both faces are hit.  A triangle without area -- e1 x e2 == (0, 0, 0) as computed by v_cross, which
  * covers two equal vertices and collinear lattice points -- is never hit: the sign tests above
@@ -429,6 +430,10 @@ static inline hit_t ray_triangle(v3 o, v3 d, v3 v0, v3 v1, v3 v2) {
   if (!(vn * s >= 0.0f) || !((un + vn) * s <= det * s)) return h;
   float tn = v_dot(e2, q);
   if (!(tn * s >= 0.0f)) return h;
+  /* A ray that runs in the triangle's plane to within rounding (|sin| of its angle to the plane
+   * below 2^-20): det is then rounding residue, and so is everything divided by it.  Tested last,
+   * so only a candidate that would otherwise be accepted pays for it. */
+  if (!(det * det > 0x1p-40f * (v_dot(e1, e1) * v_dot(p, p)))) return h;
   h.hit = 1;
   h.dst = tn / det;
   h.point = v_fma(d, h.dst, o);

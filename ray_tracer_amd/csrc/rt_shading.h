@@ -132,6 +132,9 @@ __device__ __forceinline__ void triangle_candidate(const float4 *__restrict__ T,
   if (!(vn * s >= 0.0f) || !((un + vn) * s <= det * s)) return;
   const float tn = dot(e2, q);
   if (!(tn * s >= 0.0f)) return;
+  // a ray that runs in the triangle's plane to within rounding: det is residue (tested last, so
+  // only a candidate that would otherwise be accepted pays for it)
+  if (!(det * det > 0x1p-40f * (dot(e1, e1) * dot(p, p)))) return;
   const float t = ieee_div(tn, det);
   if (t < best.dst || (t == best.dst && idx < best.idx)) {
     best.dst = t;

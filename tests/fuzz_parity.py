@@ -58,6 +58,9 @@ def random_case(rng):
         s[12:15] = rng.uniform(0.5, 1.0, 3)                                # specular colour
         s[15] = float(rng.choice([0.0, 0.2, 1.0]))                         # specular probability
         sph[i] = s
+    if n > 3 and rng.random() < 0.3:          # coincident spheres (every hit of them is a tie), a point sphere
+        sph[n - 1, 0:4] = sph[n - 2, 0:4]
+        sph[n - 3, 3] = 0.0
     ior = None
     if rng.random() < 0.4:
         ior = np.where(rng.random(n) < 0.4, np.float32(1.5), np.float32(0.0)).astype(np.float32)
@@ -68,7 +71,10 @@ def random_case(rng):
         v = (rng.uniform(-5.0, 5.0, (nv, 3)) + np.array([0.0, 1.0, -8.0])).astype(np.float32)
         if lattice:
             v = np.rint(v).astype(np.float32)
-        t = rng.integers(0, nv, (int(rng.integers(1, 60)), 3)).astype(np.uint32)
+        t = rng.integers(0, nv, (int(rng.choice([1, 5, 20, 59, 300])), 3)).astype(np.uint32)
+        if len(t) > 4 and rng.random() < 0.5:  # the same triangle twice, and once more with its corners rotated
+            t[-1] = t[0]
+            t[-2] = t[1][[1, 2, 0]]
         mesh = (v, t, rt.matte(0.6, 0.5, 0.4, smoothness=float(rng.choice([0.0, 0.8])),
                                specular_probability=float(rng.choice([0.0, 0.3]))))
     tex = None

@@ -582,6 +582,29 @@ def test_triangles_without_area_are_never_hit(oracle, accel):
     assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
 
 
+@pytest.mark.parametrize("accel", [rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH])
+def test_rays_in_the_plane_of_a_triangle_miss_it(oracle, accel):
+    """A triangle whose plane holds the camera: every primary ray towards it runs IN that plane, the
+    determinant of the triangle test is rounding residue, and without the rule that such a ray misses
+    the in-order loop reported residue hits at distance 0 that the tree search did not.  (Found by
+    tests/fuzz_parity.py on an integer lattice.)"""
+    w, h = 60, 77
+    ubo = rt.make_ubo(w, h, 2, 3, diverge=0.0)
+    sph = rt.default_scene()[:2].copy()
+    sph[0, :4] = (0, -1000.238, 0, 1000)
+    sph[1, :4] = (3, 3, -9, 0.5)
+    v = np.array([[-3, 2, -7], [-5, 5, -12], [-2, -2, -4],      # n = (-11, 1, 5), n . v0 = 0: through the origin
+                  [-3, -3, -7], [3, -3, -7], [0, 3, -7]], dtype=np.float32)
+    t = np.array([[0, 1, 2], [3, 4, 5]], dtype=np.uint32)
+    mat = rt.matte(0.7, 0.6, 0.4, smoothness=0.5, specular_probability=0.5)
+    want = oracle.render(ubo, sph, w, h, 851, 1, 1, mesh=(v, t, mat))
+    assert not (want["ids"] == 2).any() and (want["ids"] == 3).sum() > 100
+    got = gpu_render_mesh(ubo, sph, (v, t, mat), w, h, rt.MODE_MEGAKERNEL_NESTED, rt.FLAG_STRICT_MATH | accel, 851, 1, 1)
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+
+
 def test_mesh_only_scene_and_removal(oracle):
     w, h = 96, 64
     ubo = rt.make_ubo(w, h, 1, 4)
