@@ -14,9 +14,9 @@
 // whose origin is |oc| away from a sphere of radius r the discriminant carries an
 // absolute error of a few ulp of |oc|^2, so the float test reports hits for rays that
 // pass up to ~3 eps |oc|^2 / r OUTSIDE the sphere.  A tight box would cull those.  Each
-// leaf box is therefore grown by r * alpha with alpha = 4.8e-7 * D^2 / r^2, where D bounds
+// leaf box is therefore a cube of half-width sqrt(r^2 + 9.6e-7 D^2) + r / 1024, where D bounds
 // the distance from the sphere to any ray origin (camera and the region the ordinary-
-// sized spheres occupy), clamped to [2^-10, 0.5].
+// sized spheres occupy).
 //
 // Oversized spheres (radius above a tenth of the extent of all centres, at most 16 of them:
 // a ground sphere, a sky dome) stay out of the tree: their box would cover every ancestor
@@ -102,9 +102,12 @@ __global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restric
         const float far = fmaxf(fabsf(c[k] - bp.blo[k]), fabsf(c[k] - bp.bhi[k]));
         d2 += far * far;
       }
-      float alpha = 4.8e-7f * d2 / fmaxf(r * r, 1e-30f);
-      alpha = fminf(fmaxf(alpha, 0x1p-10f), 0.5f);
-      const float h = r + r * alpha + 1e-30f;
+      // The float test accepts a ray when its computed discriminant a (r^2 - dist^2) + error is >= 0,
+      // with |error| up to a few ulp of a |oc|^2: rays pass that run up to sqrt(r^2 + 9.6e-7 D^2) from
+      // the centre.  For an ordinary sphere that is r (1 + 4.8e-7 D^2 / r^2); for a tiny one (down to
+      // radius 0, which the in-order loop does hit with rays aimed at its centre) it is ~1e-3 D,
+      // however small r is.  Plus r / 1024 for the slab test's own rounding.
+      const float h = sqrtf(__builtin_fmaf(r, r, 9.6e-7f * d2)) + r * 0x1p-10f + 1e-30f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         lo[k] = c[k] - h;

@@ -58,6 +58,11 @@ def random_case(rng):
         s[12:15] = rng.uniform(0.5, 1.0, 3)                                # specular colour
         s[15] = float(rng.choice([0.0, 0.2, 1.0]))                         # specular probability
         sph[i] = s
+    if n > 1 and rng.random() < 0.15:         # the camera inside a sphere
+        sph[1, 0:4] = [0.0, 0.0, 0.0, float(rng.choice([0.5, 3.0]))] if lattice else [0.1, -0.2, 0.3, 2.5]
+    if n > 2 and rng.random() < 0.1:          # extremes of size
+        sph[2, 0:4] = [float(rng.uniform(-1e5, 1e5)), float(rng.uniform(-1e5, 1e5)), -3e5, 1e5]
+        sph[n - 1, 3] = 1e-3
     if n > 3 and rng.random() < 0.3:          # coincident spheres (every hit of them is a tie), a point sphere
         sph[n - 1, 0:4] = sph[n - 2, 0:4]
         sph[n - 3, 3] = 0.0
@@ -121,6 +126,27 @@ def run_case(c):
     for k in range(c["calls"]):
         rays_want += int(oracle.render(c["ubo"], c["sph"], c["w"], c["h"], first_frame=c["first"] + k * c["frames"],
                                        n_frames=c["frames"], mesh=c["mesh"], texture=c["tex"], ior=c["ior"])["rays"])
+    if c["mesh"] is None and c["tex"] is None and c["ior"] is None and c["calls"] == 1 and c["sph"].shape[0] <= 1024:
+        # the entry point that allocates nothing must produce the same bits (it always searches by brute force)
+        import torch
+        dev = torch.device("cuda", 0)
+        d_sph = torch.from_numpy(np.ascontiguousarray(c["sph"])).to(dev)
+        d_acc = torch.zeros((c["h"], c["w"], 4), dtype=torch.float32, device=dev)
+        d_img = torch.zeros((c["h"], c["w"], 4), dtype=torch.uint8, device=dev)
+        d_ids = torch.full((c["h"], c["w"]), -1, dtype=torch.int32, device=dev)
+        d_rays = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        rt.render_static(c["w"], c["h"], c["ubo"], d_sph.data_ptr(), c["sph"].shape[0], d_acc.data_ptr(),
+                         d_img.data_ptr(), d_ids.data_ptr(), d_rays.data_ptr(), first_frame=c["first"],
+                         n_frames=c["frames"], flags=rt.FLAG_STRICT_MATH | (rt.FLAG_ACCUM_LINEAR if c.get("linear") else 0))
+        torch.cuda.synchronize()
+        sa = d_acc.cpu().numpy().view(np.uint32)
+        wa = np.asarray(want["accum"], dtype=np.float32).view(np.uint32)
+        both_nan = np.isnan(d_acc.cpu().numpy()) & np.isnan(want["accum"])
+        if not np.array_equal(np.where(both_nan, 0, sa), np.where(both_nan, 0, wa)):
+            return ["rt_render_static: accum differs"]
+        if not np.array_equal(d_ids.cpu().numpy(), want["ids"]) or int(d_rays.item()) != rays_want:
+            return ["rt_render_static: ids or rays differ"]
     a = np.asarray(got["accum"], dtype=np.float32).view(np.uint32)
     b = np.asarray(want["accum"], dtype=np.float32).view(np.uint32)
     nan_ok = np.isnan(got["accum"]) & np.isnan(want["accum"])   # log(0) draws: NaN on both sides, payload aside

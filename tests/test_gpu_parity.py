@@ -394,6 +394,26 @@ def test_lbvh_rays_with_a_zero_direction_component(oracle, mode):
     assert np.array_equal(fast["ids"][:, w // 2], want["ids"][:, w // 2])
 
 
+def test_lbvh_finds_a_sphere_of_radius_zero(oracle):
+    """The in-order loop hits a sphere of radius 0 with rays aimed at its centre (the discriminant
+    comes out as +0 or as positive residue), so the tree search has to as well: its leaf box is sized
+    by what the float test accepts, ~1e-3 of the scene, not by the radius.  (Found by tests/fuzz_parity.py.)"""
+    w, h = 40, 104
+    ubo = rt.make_ubo(w, h, 1, 3, diverge=0.0)
+    sph = np.repeat(rt.default_scene()[:1], 20, axis=0).copy()
+    rng = np.random.default_rng(11)
+    sph[:, 0:3] = np.rint(rng.uniform(-6.0, 6.0, (20, 3)) + np.array([0.0, 0.0, -12.0]))
+    sph[:, 3] = 0.0
+    sph[::4, 3] = 1.0
+    want = oracle.render(ubo, sph, w, h, 929, 2, 1)
+    tiny_hits = int(np.isin(want["ids"], np.nonzero(sph[:, 3] == 0.0)[0]).sum())
+    assert tiny_hits >= 1, "the scene is meant to contain pixels that hit a point sphere"
+    got = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL_NESTED, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH, 929, 2, 1)
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+
+
 def test_lbvh_equals_brute_force_on_gpu_at_scale():
     """10k spheres, fast math: the LBVH and the brute-force kernels trace identical paths."""
     w, h = 640, 360
