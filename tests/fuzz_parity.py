@@ -93,8 +93,36 @@ def random_case(rng):
     first = int(rng.integers(0, 1000))
     calls = int(rng.choice([1, 1, 2, 3]))   # several launches: the later ones run tile-ordered forms
     linear = bool(rng.random() < 0.2)
+    # what changes between the launches of a case: nothing, the camera, a sphere, or the mesh's vertices
+    edits = [str(rng.choice(["none", "none", "camera", "sphere", "mesh"])) for _ in range(calls)]
+    edits[0] = "none"
+    edit_seed = int(rng.integers(0, 1 << 30))
     return dict(w=w, h=h, ubo=ubo, sph=sph, ior=ior, mesh=mesh, tex=tex, mode=mode, search=search,
-                first=first, frames=frames, calls=calls, linear=linear, lattice=lattice)
+                first=first, frames=frames, calls=calls, linear=linear, lattice=lattice, edits=edits, edit_seed=edit_seed)
+
+
+def scenes_of(c):
+    """(ubo, spheres, mesh) in force at each launch of the case."""
+    rng = np.random.default_rng(c.get("edit_seed", 0))
+    ubo, sph, mesh = c["ubo"].copy(), c["sph"].copy(), c["mesh"]
+    out = []
+    for k in range(c["calls"]):
+        kind = c.get("edits", ["none"] * c["calls"])[k]
+        if kind == "camera":
+            spp, bounces = int(ubo[40]), int(ubo[41])
+            new = rt.make_ubo(c["w"], c["h"], spp, bounces, pitch=float(rng.uniform(-0.4, 0.4)),
+                              yaw=float(rng.uniform(-1.0, 1.0)), diverge=float(ubo[67]), defocus=float(ubo[66]),
+                              sun_intensity=float(ubo[65]))
+            ubo = new
+        elif kind == "sphere":
+            sph = sph.copy()
+            j = int(rng.integers(0, sph.shape[0]))
+            sph[j, 0:3] += rng.uniform(-1.0, 1.0, 3).astype(np.float32)
+        elif kind == "mesh" and mesh is not None:
+            v = (mesh[0] + rng.uniform(-0.3, 0.3, mesh[0].shape)).astype(np.float32)
+            mesh = (v, mesh[1], mesh[2])
+        out.append((ubo, sph, mesh, kind))
+    return out
 
 
 def run_case(c):
@@ -102,12 +130,15 @@ def run_case(c):
     amode = oracle.ACCUM_LINEAR if c.get("linear") else oracle.ACCUM_GAMMA
     want = None
     acc = img = None
+    scenes = scenes_of(c)
+    rays_want = 0
     for k in range(c["calls"]):
-        want = oracle.render(c["ubo"], c["sph"], c["w"], c["h"], first_frame=c["first"] + k * c["frames"],
-                             n_frames=c["frames"], mesh=c["mesh"], texture=c["tex"], ior=c["ior"], accum=acc, rgba8=img,
+        ubo_k, sph_k, mesh_k, _ = scenes[k]
+        want = oracle.render(ubo_k, sph_k, c["w"], c["h"], first_frame=c["first"] + k * c["frames"],
+                             n_frames=c["frames"], mesh=mesh_k, texture=c["tex"], ior=c["ior"], accum=acc, rgba8=img,
                              accum_mode=amode)
         acc, img = want["accum"], want["rgba8"]
-    rays_want = 0
+        rays_want += int(want["rays"])
     with rt.Renderer(c["w"], c["h"], mode=c["mode"], flags=flags) as r:
         r.set_params(c["ubo"])
         r.set_spheres(c["sph"])
@@ -119,13 +150,18 @@ def run_case(c):
             t = c["tex"]
             r.set_texture(t["rgba8"], t["first_prim"], t["n_prims"], t["mapping"], t["scale"], t["srgb"])
         for k in range(c["calls"]):
+            ubo_k, sph_k, mesh_k, kind = scenes[k]
+            if kind == "camera":
+                r.set_params(ubo_k)
+            elif kind == "sphere":
+                r.set_spheres(sph_k)
+                if c["ior"] is not None:
+                    r.set_dielectric(c["ior"])   # (the table belongs to the sphere set it was given for)
+            elif kind == "mesh" and mesh_k is not None:
+                r.set_mesh(*mesh_k)
             r.render(c["first"] + k * c["frames"], c["frames"], 1)
         r.sync()
         got = dict(accum=r.read_accum(), rgba8=r.read_rgba8(), ids=r.read_primary_ids(), rays=int(r.stats().rays))
-    # the oracle counts segments per call; the library since the context was created
-    for k in range(c["calls"]):
-        rays_want += int(oracle.render(c["ubo"], c["sph"], c["w"], c["h"], first_frame=c["first"] + k * c["frames"],
-                                       n_frames=c["frames"], mesh=c["mesh"], texture=c["tex"], ior=c["ior"])["rays"])
     if c["mesh"] is None and c["tex"] is None and c["ior"] is None and c["calls"] == 1 and c["sph"].shape[0] <= 1024:
         # the entry point that allocates nothing must produce the same bits (it always searches by brute force)
         import torch
@@ -172,7 +208,7 @@ def main():
         tag = (f"case {i} (seed {seed}): {c['w']}x{c['h']} spheres {c['sph'].shape[0]} mode {c['mode']} search {c['search']} "
                f"spp {int(c['ubo'][40])} bounces {int(c['ubo'][41])} frames {c['frames']} x {c['calls']} "
                f"glass {c['ior'] is not None} mesh {c['mesh'] is not None} tex {c['tex'] is not None} "
-               f"lattice {c['lattice']} linear {c['linear']}")
+               f"lattice {c['lattice']} linear {c['linear']} edits {c['edits']}")
         if problems:
             print("MISMATCH", tag, problems, flush=True)
             return 1
