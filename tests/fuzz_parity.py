@@ -96,9 +96,10 @@ def random_case(rng):
     # what changes between the launches of a case: nothing, the camera, a sphere, or the mesh's vertices
     edits = [str(rng.choice(["none", "none", "camera", "sphere", "mesh"])) for _ in range(calls)]
     edits[0] = "none"
+    fast_check = bool(rng.random() < 0.5)
     edit_seed = int(rng.integers(0, 1 << 30))
     return dict(w=w, h=h, ubo=ubo, sph=sph, ior=ior, mesh=mesh, tex=tex, mode=mode, search=search,
-                first=first, frames=frames, calls=calls, linear=linear, lattice=lattice, edits=edits, edit_seed=edit_seed)
+                first=first, frames=frames, calls=calls, linear=linear, lattice=lattice, edits=edits, edit_seed=edit_seed, fast_check=fast_check)
 
 
 def scenes_of(c):
@@ -183,6 +184,34 @@ def run_case(c):
             return ["rt_render_static: accum differs"]
         if not np.array_equal(d_ids.cpu().numpy(), want["ids"]) or int(d_rays.item()) != rays_want:
             return ["rt_render_static: ids or rays differ"]
+    if c.get("fast_check"):
+        # fast math has no oracle, but it has a property: the closest hit does not depend on the order
+        # in which primitives are visited, and every organisation runs the same device functions per
+        # path, so brute force and LBVH, megakernel, nested and wavefront must all produce the same bits
+        ref = None
+        for mode in (rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT):
+            for search in (rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH):
+                with rt.Renderer(c["w"], c["h"], mode=mode, flags=search) as r:
+                    r.set_params(c["ubo"])
+                    r.set_spheres(c["sph"])
+                    if c["ior"] is not None:
+                        r.set_dielectric(c["ior"])
+                    if c["mesh"] is not None:
+                        r.set_mesh(*c["mesh"])
+                    if c["tex"] is not None:
+                        t = c["tex"]
+                        r.set_texture(t["rgba8"], t["first_prim"], t["n_prims"], t["mapping"], t["scale"], t["srgb"])
+                    for k in range(c["calls"]):
+                        r.render(c["first"] + k * c["frames"], c["frames"], 1)
+                    r.sync()
+                    acc = r.read_accum()
+                    cur = (np.where(np.isnan(acc), np.float32(0), acc).view(np.uint32).copy(), r.read_primary_ids().copy(),
+                           int(r.stats().rays))
+                if ref is None:
+                    ref = cur
+                elif not (np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1]) and ref[2] == cur[2]):
+                    return [f"fast math: mode {mode} search {search} differs from megakernel / brute force "
+                            f"({int((ref[0] != cur[0]).any(axis=-1).sum())} pixels, rays {ref[2]} vs {cur[2]})"]
     a = np.asarray(got["accum"], dtype=np.float32).view(np.uint32)
     b = np.asarray(want["accum"], dtype=np.float32).view(np.uint32)
     nan_ok = np.isnan(got["accum"]) & np.isnan(want["accum"])   # log(0) draws: NaN on both sides, payload aside
