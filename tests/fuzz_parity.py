@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised strict-mode parity runs: HIP kernels (through the C ABI) against the CPU oracle.
 
-    python tests/fuzz_parity.py [cases] [seed]
+    python tests/fuzz_parity.py [cases] [seed]        (FUZZ_BIG=1: larger images, ordered two-kernel launches)
 
 Not collected by pytest (a long-running hunt for rare mismatches, run by hand on a GPU box).
 Every case draws a scene (1 to 60 spheres of random size and material, some of them glass; sometimes
@@ -98,6 +98,13 @@ def random_case(rng):
     edits[0] = "none"
     fast_check = bool(rng.random() < 0.5)
     edit_seed = int(rng.integers(0, 1 << 30))
+    if os.environ.get("FUZZ_BIG"):   # larger images, enough samples for the ordered two-kernel launches
+        w, h = int(rng.integers(200, 420)), int(rng.integers(150, 300))
+        ubo = rt.make_ubo(w, h, 8, int(rng.choice([4, 12])), pitch=float(rng.uniform(-0.3, 0.3)),
+                          yaw=float(rng.uniform(-0.5, 0.5)), sun_intensity=float(rng.choice([0.0, 2.0])))
+        frames, calls, mode = int(rng.choice([4, 8])), 3, rt.MODE_MEGAKERNEL
+        edits = ["none"] * calls
+        fast_check = False
     return dict(w=w, h=h, ubo=ubo, sph=sph, ior=ior, mesh=mesh, tex=tex, mode=mode, search=search,
                 first=first, frames=frames, calls=calls, linear=linear, lattice=lattice, edits=edits, edit_seed=edit_seed, fast_check=fast_check)
 
