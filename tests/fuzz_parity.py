@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised strict-mode parity runs: HIP kernels (through the C ABI) against the CPU oracle.
 
-    python tests/fuzz_parity.py [cases] [seed]        (FUZZ_BIG=1: larger images, ordered two-kernel launches)
+    python tests/fuzz_parity.py [cases] [seed]        (FUZZ_BIG=1: larger images, ordered two-kernel launches;
+                                                       FUZZ_DEEP=1: thousands of primitives, brute force against LBVH)
 
 Not collected by pytest (a long-running hunt for rare mismatches, run by hand on a GPU box).
 Every case draws a scene (1 to 60 spheres of random size and material, some of them glass; sometimes
@@ -234,7 +235,82 @@ def run_case(c):
     return problems
 
 
+def deep_case(rng):
+    """FUZZ_DEEP=1: thousands of primitives, too many for the oracle.  The library's brute-force
+    search (which the other cases pin to the oracle) against its LBVH search, strict math."""
+    w, h = int(rng.integers(40, 100)), int(rng.integers(40, 100))
+    ubo = rt.make_ubo(w, h, int(rng.choice([1, 2])), int(rng.choice([2, 5])), yaw=float(rng.uniform(-0.3, 0.3)))
+    n = int(rng.choice([300, 1000, 3000, 8000]))
+    base = rt.default_scene()
+    sph = np.repeat(base[:1], n, axis=0).copy()
+    kind = str(rng.choice(["uniform", "clustered", "lattice", "line"]))
+    if kind == "uniform":
+        sph[:, 0:3] = rng.uniform(-20, 20, (n, 3)) + np.array([0, 0, -30.0])
+    elif kind == "clustered":   # many centres in the same Morton cell, some identical
+        centres = rng.uniform(-15, 15, (8, 3)) + np.array([0, 0, -30.0])
+        sph[:, 0:3] = centres[rng.integers(0, 8, n)] + rng.normal(0, 0.05, (n, 3))
+        sph[n // 2:, 0:3] = sph[: n - n // 2, 0:3]
+    elif kind == "lattice":
+        sph[:, 0:3] = np.rint(rng.uniform(-10, 10, (n, 3))) + np.array([0, 0, -25.0])
+    else:                       # a line: the most unbalanced tree Morton codes can give
+        sph[:, 0] = np.linspace(-30, 30, n); sph[:, 1] = 0.0; sph[:, 2] = -30.0
+    sph[:, 3] = rng.uniform(0.05, 0.6, n)
+    sph[:, 4:7] = rng.uniform(0.2, 1.0, (n, 3))
+    sph[:, 7] = rng.choice([0.0, 1.0], n)
+    sph[:, 15] = rng.choice([0.0, 0.5], n)
+    if rng.random() < 0.5:
+        sph[0, 0:4] = [0.0, -1030.0, 0.0, 1000.0]
+    mesh = None
+    if rng.random() < 0.5:
+        nv = int(rng.choice([50, 500, 3000]))
+        v = (rng.uniform(-15, 15, (nv, 3)) + np.array([0, 0, -30.0])).astype(np.float32)
+        nt = int(rng.choice([500, 4000]))
+        a = rng.integers(0, nv, nt)
+        t = np.stack([a, (a + rng.integers(1, 4, nt)) % nv, (a + rng.integers(4, 9, nt)) % nv], axis=1).astype(np.uint32)
+        mesh = (v, t, rt.matte(0.6, 0.5, 0.4, smoothness=0.5, specular_probability=0.3))
+    return dict(w=w, h=h, ubo=ubo, sph=sph.astype(np.float32), mesh=mesh, first=int(rng.integers(0, 100)), kind=kind)
+
+
+def run_deep(c):
+    out = []
+    for search in (rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH):
+        with rt.Renderer(c["w"], c["h"], mode=rt.MODE_MEGAKERNEL, flags=rt.FLAG_STRICT_MATH | search) as r:
+            r.set_params(c["ubo"])
+            r.set_spheres(c["sph"])
+            if c["mesh"] is not None:
+                r.set_mesh(*c["mesh"])
+            r.render(c["first"], 2, 1)
+            r.sync()
+            acc = r.read_accum()
+            out.append((np.where(np.isnan(acc), np.float32(0), acc).view(np.uint32).copy(), r.read_primary_ids().copy(),
+                        int(r.stats().rays), r.stats().bvh_height))
+    a, b = out
+    problems = []
+    if not np.array_equal(a[0], b[0]):
+        problems.append(f"accum differs in {int((a[0] != b[0]).any(axis=-1).sum())} pixels")
+    if not np.array_equal(a[1], b[1]):
+        problems.append(f"ids differ in {int((a[1] != b[1]).sum())} pixels")
+    if a[2] != b[2]:
+        problems.append(f"rays {a[2]} != {b[2]}")
+    return problems, b[3]
+
+
 def main():
+    if os.environ.get("FUZZ_DEEP"):
+        cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+        for i in range(cases):
+            c = deep_case(np.random.default_rng([seed, i, 77]))
+            problems, height = run_deep(c)
+            tag = (f"deep case {i} (seed {seed}): {c['w']}x{c['h']} spheres {c['sph'].shape[0]} {c['kind']} "
+                   f"triangles {0 if c['mesh'] is None else c['mesh'][1].shape[0]} tree height {height}")
+            if problems:
+                print("MISMATCH", tag, problems, flush=True)
+                return 1
+            if i % 5 == 0:
+                print("ok", tag, flush=True)
+        print(f"{cases} deep cases, no mismatch", flush=True)
+        return 0
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     for i in range(cases):
