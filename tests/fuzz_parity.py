@@ -86,8 +86,10 @@ def random_case(rng):
     tex = None
     if rng.random() < 0.3:
         tw, th = int(rng.integers(1, 20)), int(rng.integers(1, 20))
-        tex = dict(rgba8=rng.integers(0, 256, (th, tw, 4), dtype=np.uint8), first_prim=0,
-                   n_prims=int(rng.integers(1, n + 1)), mapping=int(rng.integers(0, 2)),
+        n_all = n + (0 if mesh is None else len(mesh[1]))
+        first_prim = int(rng.integers(0, n_all))          # spheres, triangles, or a range across both
+        tex = dict(rgba8=rng.integers(0, 256, (th, tw, 4), dtype=np.uint8), first_prim=first_prim,
+                   n_prims=int(rng.integers(1, n_all - first_prim + 1)), mapping=int(rng.integers(0, 2)),
                    scale=(float(rng.uniform(0.05, 2.0)), float(rng.uniform(0.05, 2.0))), srgb=bool(rng.integers(0, 2)))
     mode = int(rng.choice([rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT]))
     search = int(rng.choice([rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH, 0]))
