@@ -168,8 +168,8 @@ def apply_scene(r, rt, scene):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 20; 10 for configs 2 and 4)")
-    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps (default: 3; 2 for configs 2 and 4)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 100; 10 for configs 2 and 4)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps (default: 30; 2 for configs 2 and 4)")
     ap.add_argument("--config", type=int, default=1, choices=sorted(WORKLOADS))
     ap.add_argument("--mode", choices=["megakernel", "wavefront", "nested"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,10 +186,13 @@ def main() -> None:
     args = ap.parse_args()
     wl = WORKLOADS[args.config]
     heavy = args.config in (2, 4)
+    # The light workloads take about a millisecond per step, and the device needs ~20 ms of work to
+    # reach its clocks (launch times of the 1920x1080 frame fall from 1.24 to 1.10 ms over the first
+    # 18 launches of a process, whatever the launch order does): 30 untimed and 100 timed steps.
     if args.steps <= 0:
-        args.steps = 10 if heavy else 20
+        args.steps = 10 if heavy else 100
     if args.warmup < 0:
-        args.warmup = 2 if heavy else 3
+        args.warmup = 2 if heavy else 30
 
     import numpy as np
     import torch
@@ -466,11 +469,6 @@ def main() -> None:
                 "algorithmic_flops_per_launch": flops,
                 "note": "FP32 vector issue bound (no MFMA in a path tracer); HBM traffic is ~50 B/pixel/frame",
             }
-            if args.mode == "megakernel" and args.config == 1:
-                roof["kernels_per_launch"] = ("two k_mega_regen kernels side by side on two streams: the tiles with the "
-                                              "longest chains in the plain loop, the rest in the batched loop; "
-                                              "launch_ms is the HIP-event time around both, and a kernel trace lists "
-                                              "each with about that duration")
         out = {
             "metric": "Mrays/sec (all bounces)",
             "value": total_rays / elapsed / 1e6,

@@ -165,9 +165,7 @@ int rt_set_dielectric(rt_ctx *ctx, const float *ior, uint32_t count);
  * first_frame + frame_stride, ...  (main.cpp:1028 increments it by one per
  * dispatch).  Every pixel is shaded (ceil-div grid with a bounds guard).
  * Megakernel modes are asynchronous: the call returns after enqueueing on the context's
- * stream.  A launch may run part of its tiles on a second stream the context owns; that work
- * is forked from and joined back into the context's stream with events, so whatever the
- * caller orders against the context's stream is ordered against all of it.  RT_MODE_WAVEFRONT reads the live-path count back every few iterations to decide
+ * stream.  RT_MODE_WAVEFRONT reads the live-path count back every few iterations to decide
  * how many more stages to launch, so the call blocks for most of the frame. */
 int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride);
 

@@ -71,10 +71,6 @@ int guarded(const char *who, F body) {
 struct rt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  // the context's own second stream: a launch that is two kernels side by side forks to it from
-  // `stream` and joins back, so callers see one stream as before
-  rt::SideStream side{nullptr, nullptr, nullptr};
-  bool have_side = false;
   uint32_t width = 0, height = 0, mode = 0, flags = 0;
   size_t n_pixels = 0;
 
@@ -290,44 +286,6 @@ static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
     return bail(e, "hipMalloc(tile order)");
   if ((e = hipMemsetAsync(c->d_tile_cost, 0, c->n_tiles * sizeof(uint32_t), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(tile cost)");
-  if ((e = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking)) != hipSuccess)
-    return bail(e, "hipStreamCreate(side stream)");
-  if ((e = hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming)) != hipSuccess)
-    return bail(e, "hipEventCreate(fork)");
-  if ((e = hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming)) != hipSuccess)
-    return bail(e, "hipEventCreate(join)");
-  // Two launches side by side only pay if the two streams really run side by side.  Streams
-  // share a few hardware queues, and two streams that landed on one queue (or run under a tool
-  // that serialises kernels) would make such a launch the SUM of its two kernels, nearly twice
-  // the single-kernel form.  So: two 200 us one-wave kernels, forked and joined exactly like a
-  // render (which costs ~30 us by itself); side by side they take ~0.23 ms, in a row 0.43.
-  {
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    float ms = 1e9f;
-    e = hipEventCreate(&t0);
-    if (e == hipSuccess) e = hipEventCreate(&t1);
-    // (the first launch of a process also loads the code and wakes the queues: not timed)
-    if (e == hipSuccess) e = rt::launch_spin(1, c->side.stream);
-    if (e == hipSuccess) e = rt::launch_spin(1, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->side.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipEventRecord(t0, c->stream);
-    if (e == hipSuccess) e = hipEventRecord(c->side.fork, c->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->side.stream, c->side.fork, 0);
-    if (e == hipSuccess) e = rt::launch_spin(20000, c->side.stream);
-    if (e == hipSuccess) e = hipEventRecord(c->side.join, c->side.stream);
-    if (e == hipSuccess) e = rt::launch_spin(20000, c->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->side.join, 0);
-    if (e == hipSuccess) e = hipEventRecord(t1, c->stream);
-    if (e == hipSuccess) e = hipEventSynchronize(t1);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t0, t1);
-    if (t0) hipEventDestroy(t0);
-    if (t1) hipEventDestroy(t1);
-    if (e != hipSuccess) return bail(e, "side stream check");
-    c->have_side = ms < 0.32f;
-    if (std::getenv("RT_SIDE_STREAM_REPORT")) std::fprintf(stderr, "rt_create: side stream check %.3f ms\n", ms);
-    if (const char *env = std::getenv("RT_SIDE_STREAM")) c->have_side = env[0] != '0';
-  }
   if (const char *env = std::getenv("RT_TILE_ORDER")) c->use_tile_order = env[0] != '0';
   if (const char *env = std::getenv("RT_TILE_PROBE")) c->use_probe = env[0] != '0';
   int rc = rt_clear(c);
@@ -343,12 +301,6 @@ int rt_destroy(rt_ctx *c) {
   if (!c) return RT_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  if (c->side.stream) {
-    hipStreamSynchronize(c->side.stream);
-    hipStreamDestroy(c->side.stream);
-  }
-  if (c->side.fork) hipEventDestroy(c->side.fork);
-  if (c->side.join) hipEventDestroy(c->side.join);
   if (c->own_accum && c->d_accum) hipFree(c->d_accum);
   if (c->d_rgba8) hipFree(c->d_rgba8);
   if (c->d_ids) hipFree(c->d_ids);
@@ -759,8 +711,7 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
       launches = 1;
     } else {
       const bool nested = degenerate || c->mode == RT_MODE_MEGAKERNEL_NESTED;
-      he = rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream,
-                                 c->have_side ? &c->side : nullptr);
+      he = rt::launch_megakernel(nested, strict, c->use_bvh, c->P, S, F, O, c->stream);
       launches = 1;
       ordered = !nested && c->use_tile_order;
     }

@@ -127,7 +127,6 @@ struct Outputs {
   uint32_t chain_ranks;     // k_mega_regen, mixed form: blocks below this rank run the plain loop
   uint32_t sparse_ranks;    // k_mega_regen, mixed form: tiles below this rank are spread over more waves,
   uint32_t sparse_shift;    //   2^sparse_shift (2, 4 or 8) per wave of the tile
-  uint32_t rank_base;       // k_mega_regen: rank of the launch's first tile (a launch may cover part of the order)
   uint32_t probe;           // 1: a cost probe, the tile kernels write tile_cost and nothing else
 };
 

@@ -7,17 +7,9 @@
 
 namespace rt {
 
-// A second stream (and the two events that fork from and join the caller's stream) for launches
-// that run two kernels side by side.
-struct SideStream {
-  hipStream_t stream;
-  hipEvent_t fork, join;
-};
-
-// rt_megakernel.hip.  side may be null: every launch is then a single kernel on `stream`.
+// rt_megakernel.hip
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
-                             const FrameSeq &F, const Outputs &O, hipStream_t stream,
-                             const SideStream *side = nullptr);
+                             const FrameSeq &F, const Outputs &O, hipStream_t stream);
 
 // fast math, LBVH, nested loops, plus node/sphere tallies in O.rays[1], O.rays[2]
 hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const FrameSeq &F,
@@ -43,8 +35,6 @@ hipError_t launch_fold_rays(unsigned long long *slots, unsigned long long *total
 // itself and its eight neighbours
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream,
                              uint32_t *order_near = nullptr, uint32_t tiles_x = 0);
-// a one-wave kernel that waits for `ticks` ticks of the 100 MHz wall clock (stream placement checks)
-hipError_t launch_spin(unsigned long long ticks, hipStream_t stream);
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,
                              hipStream_t stream);
 

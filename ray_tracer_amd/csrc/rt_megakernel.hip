@@ -39,7 +39,7 @@
 #define RT_REGEN_BATCHED_WAVES 7  // waves per SIMD the untextured batched loop is compiled for (72 VGPR; 6: +2 %, 8: +4 % time at 3840x2160)
 #endif
 #ifndef RT_REGEN_CHAIN_DIV
-#define RT_REGEN_CHAIN_DIV 32u  // a mixed launch runs its first n_tiles / 32 blocks through the plain loop (8..128 within 2 %)
+#define RT_REGEN_CHAIN_DIV 128u  // a mixed launch runs its first n_tiles / 128 blocks through the plain loop (1920x1080: 16: 1.127, 32: 1.113, 64: 1.108, 128: 1.105, 256: 1.106 ms)
 #endif
 #ifndef RT_REGEN_BATCH_TILES
 #define RT_REGEN_BATCH_TILES 12288u  // launches with at least this many tiles (8 x what the device holds) use the batched loop
@@ -221,11 +221,9 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
 // kRegenMixed = the plain loop for the first O.chain_ranks blocks of an ordered launch (the
 // tiles with the longest chains, which set the launch time) and the batched loop for the rest
 // (whose job is throughput).
-// kRegenChain = the plain loop for a launch that covers only the head of the order (the chain
-// tiles), run beside a batched launch of the rest.
-constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2, kRegenChain = 3;
+constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
 #ifndef RT_SPARSE_RANKS
-#define RT_SPARSE_RANKS 3
+#define RT_SPARSE_RANKS 2
 #endif
 #ifndef RT_SPARSE_FEW_TILES
 #define RT_SPARSE_FEW_TILES 4096  // 1280x720 has 3,600 tiles, 1920x1080 8,160
@@ -245,23 +243,26 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
   // brute-force search is the form tuned for a wave running alone, and the hit carries the
   // sphere's centre to the shading code instead of having it fetched again.
   constexpr bool CHAIN = !BVH;
-  // batch sizes of the batched loop: large where the whole launch runs it, small where it
-  // shares the launch with the plain loop (tiles just below the chain ranks still have long
-  // chains, which large batches stretch: 1920x1080 mixed 1.27 against 1.32 ms)
-  constexpr int SHADE_BATCH = FORM == kRegenBatched ? RT_REGEN_SHADE_BATCH : 1;
-  constexpr int END_BATCH = FORM == kRegenBatched ? RT_REGEN_END_BATCH : 8;
+  // batch sizes of the batched loop, in the mixed kernel too.  (While the chain tiles ran as full
+  // waves the mixed kernel needed small batches, 8 path ends and no gathering of hits, because the
+  // tiles just below the chain ranks still have long chains that large batches stretch; since the
+  // heaviest tiles run as sparse waves, large batches for everything else win: 1920x1080 1.156 ->
+  // 1.117 ms, and 1.105 with a chain share of 1/128 instead of 1/32.)
+  constexpr int SHADE_BATCH = FORM != kRegenPlain ? RT_REGEN_SHADE_BATCH : 1;
+  constexpr int END_BATCH = FORM != kRegenPlain ? RT_REGEN_END_BATCH : 8;
   constexpr int BLOCK = BVH ? 256 : kTileBlock;
   // Mixed form: the tiles of the first O.sparse_ranks ranks, whose chains bound the launch, are
   // spread over 2^O.sparse_shift times the waves, each with that fraction of its lanes switched
   // on (whole rows of the wave's 8x8 pixels).  What stretches the chain of the slowest lane is
   // the path-end code that runs, in nearly every iteration, for whichever OTHER lanes of its wave
   // need it; with a quarter of the lanes it runs a quarter as often.  The extra waves cost
-  // issue slots for the whole launch, so only a few tiles pay: 1920x1080 1.207 -> 1.160 ms with
-  // 3 tiles of 4 x 16 lanes; 16 tiles 1.187, 64 tiles 1.264; 8 x 8 lanes 1.17 at best.  1280x720,
-  // where the device is never full: 1.25 -> 1.09 ms with 8 x 8 lanes, 3 to 64 tiles alike.
+  // issue slots for the whole launch, so only a few tiles pay: 1920x1080 (small batches, at the
+  // time) 1.207 -> 1.160 ms with 3 tiles of 4 x 16 lanes; 16 tiles 1.187, 64 tiles 1.264; with
+  // large batches 2 tiles of 8 x 8 lanes are the optimum.  1280x720, where the device is never
+  // full: 1.25 -> 1.09 ms with 8 x 8 lanes, 3 to 64 tiles alike.
   uint32_t rank = tile_rank<BLOCK>(), tile_t = tile_thread<BLOCK>();
   bool lane_on = true;
-  if constexpr (FORM == kRegenMixed || FORM == kRegenChain) {
+  if constexpr (FORM == kRegenMixed) {
     const uint32_t k = O.sparse_shift;  // 1, 2 or 3: each wave becomes 2, 4 or 8
     const uint32_t nb = (O.sparse_ranks * 4u) << k;
     if (blockIdx.x < nb) {
@@ -275,7 +276,6 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
       tile_t = ((bb & 3u) << 6) | threadIdx.x;
     }
   }
-  if constexpr (FORM == kRegenBatched) rank += O.rank_base;  // (a launch may cover the tail of the order only)
   const bool batched = FORM == kRegenMixed ? rank >= O.chain_ranks : FORM == kRegenBatched;
   const uint32_t tile = ordered_tile(O, rank);
   uint32_t px, py;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
 
 template <bool STRICT, bool BVH, int EXT, bool APPROX>
 static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, const FrameSeq &F,
-                                const Outputs &O, hipStream_t stream, const SideStream *side) {
+                                const Outputs &O, hipStream_t stream) {
   dim3 grid((P.width + 15u) / 16u, (P.height + 15u) / 16u, 1);
   dim3 tiles(O.n_tiles, 1, 1);  // k_mega_regen and k_mega_sched take tiles from a 1-D grid
 #ifdef RT_DEBUG_TILE_LIMIT
@@ -669,12 +669,9 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
     else if (form == kRegenMixed) {
       // The tiles of the first chain_ranks ranks run the plain loop, the first sparse_ranks of
       // them in waves of 64 >> shift lanes (see the kernel); the rest run the batched loop.
-      // With a side stream these are two launches side by side: the rest then runs the batched
-      // kernel proper (71 VGPR, 7 waves per SIMD, batches of 48 hits / 24 path ends) instead of
-      // the small-batch loop inside the kernel that holds both (79 VGPR): 1920x1080 1.165 ->
-      // 1.12 ms.  The chain launch goes first and on the caller's stream, so its waves are
-      // resident from the start.  RT_SPARSE_RANKS / RT_SPARSE_SHIFT / RT_TWO_LAUNCHES=0
-      // override (measurements).
+      // (Two kernels side by side on two streams, one per loop, were measured too: 1.13 ms at
+      // 1920x1080 against 1.105 for this one kernel, whose fork and join cost nothing.)
+      // RT_SPARSE_RANKS / RT_SPARSE_SHIFT override (measurements).
       static const int sparse_env = [] {
         const char *e = getenv("RT_SPARSE_RANKS");
         return e ? (int)strtoul(e, nullptr, 10) : -1;
@@ -684,46 +681,14 @@ static hipError_t launch_mega_t(bool nested, const Params &P, const Scene &S, co
         const int v = e ? (int)strtoul(e, nullptr, 10) : -1;
         return v < 0 ? -1 : v < 1 ? 1 : v > 3 ? 3 : v;
       }();
-      static const bool two_env = [] {
-        const char *e = getenv("RT_TWO_LAUNCHES");
-        return !(e && e[0] == '0');
-      }();
-      // (forking to the side stream and joining costs ~30 us: 1280x720 at 1 spp takes 0.043 ms as
-      // one launch and 0.075 ms as two, so only launches with long chains are split)
-      const bool two = B && side && two_env && Q.chain_ranks < tiles.x && (uint64_t)P.n_spp * F.count >= 32u;
+      // launches that never fill the device: 16 tiles; others: 2 (RT_SPARSE_RANKS); 8 waves of 8 lanes each
       const bool few = O.n_tiles <= RT_SPARSE_FEW_TILES;
-      // (measured optima: one launch 3 tiles x 4 waves, two launches 2 tiles x 8; launches that
-      // never fill the device 16 tiles x 8)
-      const uint32_t sparse = sparse_env >= 0 ? (uint32_t)sparse_env : few ? 16u : two ? 2u : (uint32_t)RT_SPARSE_RANKS;
-      const uint32_t shift = shift_env >= 0 ? (uint32_t)shift_env : (few || two) ? 3u : 2u;
+      const uint32_t sparse = sparse_env >= 0 ? (uint32_t)sparse_env : few ? 16u : (uint32_t)RT_SPARSE_RANKS;
+      const uint32_t shift = shift_env >= 0 ? (uint32_t)shift_env : 3u;
       Q.sparse_ranks = sparse < Q.chain_ranks ? sparse : Q.chain_ranks;
       if (Q.sparse_ranks > tiles.x) Q.sparse_ranks = tiles.x;
       Q.sparse_shift = shift;
       const uint32_t extra = Q.sparse_ranks * 4u * ((1u << shift) - 1u);
-      if (two) {
-        hipError_t e = hipEventRecord(side->fork, stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-        if (e != hipSuccess) return e;
-        const dim3 chain_grid(Q.chain_ranks * 4u + extra, 1, 1), rest_grid((tiles.x - Q.chain_ranks) * 4u, 1, 1);
-        // The chain launch stays on the caller's stream, where nothing holds it up, and the
-        // rest goes to the side stream, which first has to see the fork event: whichever way
-        // the two queues are served, the chain waves are not the ones that start late (the
-        // other way round the launch took 2.0 instead of 1.1 ms under a kernel tracer).
-        hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenChain : kRegenPlain>), chain_grid, wave_block, 0, stream, P, S, F, Q);
-        e = hipGetLastError();
-        Outputs T = Q;
-        T.rank_base = Q.chain_ranks;
-        T.sparse_ranks = 0;
-        if (e == hipSuccess) {
-          hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenBatched : kRegenPlain>), rest_grid, wave_block, 0, side->stream, P, S, F, T);
-          e = hipGetLastError();
-        }
-        // the caller's stream continues only when both launches are done (also after a failure
-        // above: whatever reached the side stream is joined)
-        hipError_t ej = hipEventRecord(side->join, side->stream);
-        if (ej == hipSuccess) ej = hipStreamWaitEvent(stream, side->join, 0);
-        return e != hipSuccess ? e : ej;
-      }
       const dim3 mixed_tiles(wave_tiles.x + extra, 1, 1);
       hipLaunchKernelGGL((k_mega_regen<STRICT, BVH, EXT, APPROX, B ? kRegenMixed : kRegenPlain>), mixed_tiles, wave_block, 0, stream, P, S, F, Q);
     }
@@ -750,24 +715,24 @@ hipError_t launch_megakernel_counting(const Params &P, const Scene &S, const Fra
 
 template <bool STRICT, bool BVH, bool APPROX>
 static hipError_t launch_mega_e(bool nested, const Params &P, const Scene &S, const FrameSeq &F, const Outputs &O,
-                                hipStream_t stream, const SideStream *side) {
-  if (S.ior) return launch_mega_t<STRICT, BVH, kExtDielectric, APPROX>(nested, P, S, F, O, stream, side);
-  if (S.tex) return launch_mega_t<STRICT, BVH, kExtTexture, APPROX>(nested, P, S, F, O, stream, side);
-  return launch_mega_t<STRICT, BVH, kExtNone, APPROX>(nested, P, S, F, O, stream, side);
+                                hipStream_t stream) {
+  if (S.ior) return launch_mega_t<STRICT, BVH, kExtDielectric, APPROX>(nested, P, S, F, O, stream);
+  if (S.tex) return launch_mega_t<STRICT, BVH, kExtTexture, APPROX>(nested, P, S, F, O, stream);
+  return launch_mega_t<STRICT, BVH, kExtNone, APPROX>(nested, P, S, F, O, stream);
 }
 
 hipError_t launch_megakernel(bool nested, bool strict, bool bvh, const Params &P, const Scene &S,
-                             const FrameSeq &F, const Outputs &O, hipStream_t stream, const SideStream *side) {
+                             const FrameSeq &F, const Outputs &O, hipStream_t stream) {
   // fast policy without a mesh: approximate sphere distances behind exact decisions
   const bool approx = !strict && S.n_tris == 0u;
   if (strict)
-    return bvh ? launch_mega_e<true, true, false>(nested, P, S, F, O, stream, side)
-               : launch_mega_e<true, false, false>(nested, P, S, F, O, stream, side);
+    return bvh ? launch_mega_e<true, true, false>(nested, P, S, F, O, stream)
+               : launch_mega_e<true, false, false>(nested, P, S, F, O, stream);
   if (approx)
-    return bvh ? launch_mega_e<false, true, true>(nested, P, S, F, O, stream, side)
-               : launch_mega_e<false, false, true>(nested, P, S, F, O, stream, side);
-  return bvh ? launch_mega_e<false, true, false>(nested, P, S, F, O, stream, side)
-             : launch_mega_e<false, false, false>(nested, P, S, F, O, stream, side);
+    return bvh ? launch_mega_e<false, true, true>(nested, P, S, F, O, stream)
+               : launch_mega_e<false, false, true>(nested, P, S, F, O, stream);
+  return bvh ? launch_mega_e<false, true, false>(nested, P, S, F, O, stream)
+             : launch_mega_e<false, false, false>(nested, P, S, F, O, stream);
 }
 
 }  // namespace rt

@@ -327,19 +327,6 @@ __global__ __launch_bounds__(256) void k_debug_eval(int op, const float *__restr
   }
 }
 
-// one wave that does nothing for `ticks` ticks of the 100 MHz wall clock
-__global__ __launch_bounds__(64) void k_spin(unsigned long long ticks, unsigned long long *out) {
-  const unsigned long long t0 = wall_clock64();
-  unsigned long long t = t0;
-  while (t - t0 < ticks) t = wall_clock64();
-  if (out && threadIdx.x == 0) *out = t - t0;  // (never taken with out == nullptr; keeps the loop alive)
-}
-
-hipError_t launch_spin(unsigned long long ticks, hipStream_t stream) {
-  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, stream, ticks, (unsigned long long *)nullptr);
-  return hipGetLastError();
-}
-
 hipError_t launch_debug_eval(int op, const float *a, const float *b, float *out, size_t n,
                              hipStream_t stream) {
   if (n == 0) return hipSuccess;

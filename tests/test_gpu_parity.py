@@ -484,10 +484,9 @@ def test_caller_owned_accumulation_buffer_and_stream():
             assert np.max(np.abs(r.read_rgba8()[..., :3].astype(int) - want8.astype(int))) <= 1
 
 
-def test_two_kernel_launches_are_ordered_on_the_callers_stream():
-    """Launches of 32 or more samples per pixel run as two kernels, one of them on a stream the
-    context owns.  Work the caller puts on ITS stream right after rt_render must still see the
-    finished image, and the next render must see the previous one's."""
+def test_launches_are_ordered_on_the_callers_stream():
+    """Work the caller puts on its stream right after rt_render (ordered launches of the mixed form
+    here) must see the finished image, and the next render the previous one's."""
     import torch
     w, h = 320, 200
     ubo = rt.make_ubo(w, h, 8, 12, sun_intensity=2.0)
@@ -947,13 +946,12 @@ def test_fast_policy_ids_exact_on_random_scenes(oracle, accel):
 
 
 def test_regen_loop_forms_are_bit_identical():
-    """k_mega_regen has two loops (the plain one and a throughput form that gathers path ends per
-    wave) and a mixed form that runs the heaviest tiles through the first and the rest through
-    the second -- as two launches side by side, or as one kernel holding both loops -- with the
-    very heaviest tiles spread over waves of 32 / 16 / 8 lanes.  The choice is read once per
-    process (RT_REGEN_FORM and friends), so child processes render the same frames with each
-    form forced; images, ids and ray counts must be identical.  The mixed form needs a measured
-    tile order, which exists from the second launch on."""
+    """k_mega_regen has two loops (the plain one and a throughput form that gathers hits and path
+    ends per wave) and a mixed form that runs the heaviest tiles through the first and the rest
+    through the second, with the very heaviest tiles spread over waves of 32 / 16 / 8 lanes.  The
+    choice is read once per process (RT_REGEN_FORM and friends), so child processes render the
+    same frames with each form forced; images, ids and ray counts must be identical.  The mixed
+    form needs a measured tile order, which exists from the second launch on."""
     import os
     import subprocess
     import sys
@@ -977,13 +975,12 @@ def test_regen_loop_forms_are_bit_identical():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
     variants = [dict(RT_REGEN_FORM="plain"), dict(RT_REGEN_FORM="batched"),
-                dict(RT_REGEN_FORM="mixed"),                                  # two launches, 16 tiles x 8 waves
-                dict(RT_REGEN_FORM="mixed", RT_SPARSE_RANKS="0"),             # two launches, no split
+                dict(RT_REGEN_FORM="mixed"),                                  # 16 tiles x 8 waves
+                dict(RT_REGEN_FORM="mixed", RT_SPARSE_RANKS="0"),             # no split
                 dict(RT_REGEN_FORM="mixed", RT_SPARSE_RANKS="5", RT_SPARSE_SHIFT="1"),
-                dict(RT_REGEN_FORM="mixed", RT_TWO_LAUNCHES="0"),             # one kernel with both loops
-                dict(RT_REGEN_FORM="mixed", RT_TWO_LAUNCHES="0", RT_SPARSE_RANKS="200", RT_SPARSE_SHIFT="2")]
+                dict(RT_REGEN_FORM="mixed", RT_REGEN_CHAIN_DIV="2", RT_SPARSE_RANKS="200", RT_SPARSE_SHIFT="2")]
     for v in variants:
-        env = dict(os.environ, RT_REGEN_CHAIN_DIV="4", PYTHONPATH=root, **v)
+        env = dict(os.environ, PYTHONPATH=root, **{"RT_REGEN_CHAIN_DIV": "4", **v})
         res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
         assert res.returncode == 0, res.stderr
         out.append([l for l in res.stdout.splitlines() if l.startswith("DIGEST")][0])
