@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised strict-mode parity runs: HIP kernels (through the C ABI) against the CPU oracle.
 
-    python tests/fuzz_parity.py [cases] [seed]        (FUZZ_BIG=1: larger images, ordered two-kernel launches;
+    python tests/fuzz_parity.py [cases] [seed]        (FUZZ_BIG=1: larger images, ordered mixed launches with sparse waves;
                                                        FUZZ_DEEP=1: thousands of primitives, brute force against LBVH)
 
 Not collected by pytest (a long-running hunt for rare mismatches, run by hand on a GPU box).
@@ -29,7 +29,7 @@ def random_case(rng):
     bounces = int(rng.choice([1, 2, 4, 7, 12]))
     frames = int(rng.choice([1, 1, 2, 4, 8]))
     if spp * frames >= 32 and rng.random() < 0.5:
-        frames = 4   # keep most cases cheap, some above the two-kernel threshold
+        frames = 4   # keep most cases cheap, some with enough samples for the sparse-wave split
     ubo = rt.make_ubo(w, h, spp, bounces, pitch=float(rng.uniform(-0.5, 0.5)), yaw=float(rng.uniform(-3.1, 3.1)),
                       diverge=float(rng.choice([0.0, 1.0, 3.0])), defocus=float(rng.choice([0.0, 0.0, 2.0])),
                       sun_intensity=float(rng.choice([0.0, 2.0])))
@@ -101,7 +101,7 @@ def random_case(rng):
     edits[0] = "none"
     fast_check = bool(rng.random() < 0.5)
     edit_seed = int(rng.integers(0, 1 << 30))
-    if os.environ.get("FUZZ_BIG"):   # larger images, enough samples for the ordered two-kernel launches
+    if os.environ.get("FUZZ_BIG"):   # larger images, enough samples for the ordered mixed launches (sparse waves)
         w, h = int(rng.integers(200, 420)), int(rng.integers(150, 300))
         ubo = rt.make_ubo(w, h, 8, int(rng.choice([4, 12])), pitch=float(rng.uniform(-0.3, 0.3)),
                           yaw=float(rng.uniform(-0.5, 0.5)), sun_intensity=float(rng.choice([0.0, 2.0])))

@@ -4,10 +4,10 @@ the file bench.py reads its `traffic` and counter ratios from.
 
     python tools/pmc_to_json.py profiles/r2 [tag shown in the source strings]
 
-Per workload and per step of its dominant kernel (the variant with the most dispatches; where a
-step is two kernels side by side -- the 1920x1080 default-scene frame: chain tiles and the rest --
-both have that count, their counts are added, and since a counter run serialises them the
-cycles of the step come from the measured step time in bench_cfgN.json at 2.4 GHz):
+Per workload and per step of its dominant kernel (the variant with the most dispatches; if a
+step launches several kernels that share that count, their counts are added, and since a counter
+run serialises them the cycles of the step then come from the measured step time in
+bench_cfgN.json at 2.4 GHz):
   hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; FETCH_SIZE reads half the
   bytes of wide coalesced reads on gfx950), cycles = GRBM_GUI_ACTIVE / 8 XCDs,
   valu_instructions_per_simd_cycle = SQ_INSTS_VALU / (1024 SIMDs * cycles),
