@@ -312,6 +312,38 @@ def main() -> None:
         return sum(s.rays for s in st), sum(s.total_render_ms for s in st)
 
     cold_ms = None
+    # outside the timed region, rank 0 of a single-GPU run only: the other kernel organisation
+    # (configs[1] asks for "megakernel vs wavefront"), the bit-exact strict-math launch, and for
+    # LBVH scenes the traversal tallies that price a path segment in bytes.  They run BEFORE the
+    # warm-up steps rather than after the timed ones: an idle device needs ~20 ms of work to reach
+    # its clocks (the 1920x1080 frame takes 1.24 ms on the second launch of a process and 1.10 ms
+    # from the twentieth on), and with these launches first the W warm-up and K timed steps all
+    # see the device as a renderer that has been running for a moment sees it.
+    other_ms = strict_ms = None
+    bytes_per_segment = nodes_per_seg = prims_per_seg = None
+    if world == 1 and args.mode == "megakernel" and not args.no_side_runs:
+        def side(mode_, flags, frames=3):
+            with rt.Renderer(WIDTH, HEIGHT, mode=mode_, flags=flags, device=local_rank) as x:
+                apply_scene(x, rt, scene)
+                x.render(0, wl["frames"], 1)
+                x.stats()
+                t = []
+                for f in range(1, frames + 1):
+                    x.render(f * wl["frames"], wl["frames"], 1)
+                    t.append(x.stats().last_render_ms)
+                return sorted(t)[len(t) // 2], x.stats()
+        if args.config in (0, 1, 2, 3):
+            other_ms, _ = side(rt.MODE_WAVEFRONT, 0, 3 if args.config != 2 else 1)
+        strict_ms, _ = side(rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH, 3 if not heavy else 1)
+        if wl["scene"] in ("grid", "terrain"):
+            with rt.Renderer(WIDTH, HEIGHT, flags=rt.FLAG_COUNT_TRAVERSAL, device=local_rank) as x:
+                probe = dict(scene)
+                probe["ubo"] = rt.make_ubo(WIDTH, HEIGHT, 2, BOUNCES)
+                apply_scene(x, rt, probe)
+                x.render(0, 1, 1)
+                s = x.stats()
+                nodes_per_seg = s.bvh_nodes_visited / max(s.rays, 1)
+                prims_per_seg = s.bvh_spheres_tested / max(s.rays, 1)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -327,40 +359,14 @@ def main() -> None:
     kernel_ms = float(ms1 - ms0)
     st_last = renderers[0].stats()
 
-    # outside the timed region, rank 0 of a single-GPU run only: the other kernel organisation
-    # (configs[1] asks for "megakernel vs wavefront"), the bit-exact strict-math launch, and for
-    # LBVH scenes the traversal tallies that price a path segment in bytes
-    other_ms = strict_ms = None
-    bytes_per_segment = nodes_per_seg = prims_per_seg = None
     if world == 1 and args.mode == "megakernel" and not args.no_side_runs:
-        def side(mode_, flags, frames=3):
-            with rt.Renderer(WIDTH, HEIGHT, mode=mode_, flags=flags, device=local_rank) as x:
-                apply_scene(x, rt, scene)
-                x.render(0, wl["frames"], 1)
-                x.stats()
-                t = []
-                for f in range(1, frames + 1):
-                    x.render(f * wl["frames"], wl["frames"], 1)
-                    t.append(x.stats().last_render_ms)
-                return sorted(t)[len(t) // 2], x.stats()
         # first launch of a NEW context on a process whose kernels are loaded: no tile costs yet, so
         # a two-sample cost probe and the ordering pass precede the frame (all inside the figure)
         with rt.Renderer(WIDTH, HEIGHT, mode=mode, flags=0, device=local_rank) as x:
             apply_scene(x, rt, scene)
             x.render(0, wl["frames"], 1)
             cold_ms = x.stats().last_render_ms
-        if args.config in (0, 1, 2, 3):
-            other_ms, _ = side(rt.MODE_WAVEFRONT, 0, 3 if args.config != 2 else 1)
-        strict_ms, _ = side(rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH, 3 if not heavy else 1)
-        if wl["scene"] in ("grid", "terrain"):
-            with rt.Renderer(WIDTH, HEIGHT, flags=rt.FLAG_COUNT_TRAVERSAL, device=local_rank) as x:
-                probe = dict(scene)
-                probe["ubo"] = rt.make_ubo(WIDTH, HEIGHT, 2, BOUNCES)
-                apply_scene(x, rt, probe)
-                x.render(0, 1, 1)
-                s = x.stats()
-                nodes_per_seg = s.bvh_nodes_visited / max(s.rays, 1)
-                prims_per_seg = s.bvh_spheres_tested / max(s.rays, 1)
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=small)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
