@@ -312,7 +312,7 @@ def main() -> None:
         return sum(s.rays for s in st), sum(s.total_render_ms for s in st)
 
     cold_ms = None
-    # outside the timed region, rank 0 of a single-GPU run only: the other kernel organisation
+    # outside the timed region: the other kernel organisation
     # (configs[1] asks for "megakernel vs wavefront"), the bit-exact strict-math launch, and for
     # LBVH scenes the traversal tallies that price a path segment in bytes.  They run BEFORE the
     # warm-up steps rather than after the timed ones: an idle device needs ~20 ms of work to reach
@@ -321,7 +321,8 @@ def main() -> None:
     # see the device as a renderer that has been running for a moment sees it.
     other_ms = strict_ms = None
     bytes_per_segment = nodes_per_seg = prims_per_seg = None
-    if world == 1 and args.mode == "megakernel" and not args.no_side_runs:
+    # (every rank of a multi-GPU run does them too, so that each device starts its steps warm)
+    if args.mode == "megakernel" and not args.no_side_runs:
         def side(mode_, flags, frames=3):
             with rt.Renderer(WIDTH, HEIGHT, mode=mode_, flags=flags, device=local_rank) as x:
                 apply_scene(x, rt, scene)
