@@ -551,6 +551,9 @@ void Lbvh::release() {
   } while (0)
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+static bool same_bits(const std::vector<float> &a, const std::vector<float> &b) {
+  return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0);
+}
 
 int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spheres,
                 const float4 *d_tri, const float mesh_lo[3], const float mesh_hi[3], uint32_t n_tris,
@@ -663,9 +666,12 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
       BVH_HIP(hipMalloc((void **)&large_geom, kMaxLargeSpheres * sizeof(float4)));
       BVH_HIP(hipMalloc((void **)&large_prim, kMaxLargeSpheres * sizeof(uint32_t)));
     }
-    if (lg != w.up_large_geom || li != w.up_large_prim) {
-      BVH_HIP(hipMemcpy(large_geom, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
-      BVH_HIP(hipMemcpy(large_prim, li.data(), li.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // (uploads are skipped when the device already holds the same BITS: -0 is not +0 here.
+    // The copies go through the launch stream, behind any frame that still reads the old list.)
+    if (!same_bits(lg, w.up_large_geom) || li != w.up_large_prim) {
+      BVH_HIP(hipMemcpyAsync(large_geom, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+      BVH_HIP(hipMemcpyAsync(large_prim, li.data(), li.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+      BVH_HIP(hipStreamSynchronize(stream));  // lg, li (pageable host memory) must outlive the copies
       w.up_large_geom = lg;
       w.up_large_prim = li;
     }
@@ -693,7 +699,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
 
   // ---- device build ----------------------------------------------------------------------
   BVH_HIP(hipEventRecord(w.ev0, stream));
-  if (n_spheres && cr != w.up_cr) {
+  if (n_spheres && !same_bits(cr, w.up_cr)) {
     BVH_HIP(hipMemcpyAsync(w.cr, cr.data(), (size_t)n_spheres * 4 * sizeof(float),
                            hipMemcpyHostToDevice, stream));
     BVH_HIP(hipStreamSynchronize(stream));  // cr (pageable host memory) must outlive the copy
