@@ -1,7 +1,8 @@
 // Linear BVH over spheres and mesh triangles, built on the GPU.
 //
 //   1. leaf boxes (inflated, see below) + bounds of the centres       k_leaf_boxes
-//   2. 30-bit Morton code of each centre                              k_morton
+//   2. 30-bit Morton code of each centre (bits handed to the axes by   k_morton
+//      the shape of the scene)
 //   3. stable LSD radix sort of (code, index), 4 passes of 8 bits     k_rs_hist / k_rs_scan / k_rs_scatter
 //   4. Karras (2012) radix-tree hierarchy over the sorted codes,      k_hierarchy
 //      ties broken by sorted position
@@ -177,13 +178,9 @@ __global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restric
   }
 }
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
-  v = (v * 0x00010001u) & 0xFF0000FFu;
-  v = (v * 0x00000101u) & 0x0F00F00Fu;
-  v = (v * 0x00000011u) & 0xC30C30C3u;
-  v = (v * 0x00000005u) & 0x49249249u;
-  return v;
-}
+#ifndef RT_MORTON_ADAPTIVE
+#define RT_MORTON_ADAPTIVE 1  // 0: ten bits per axis on cubic cells
+#endif
 
 __global__ __launch_bounds__(kThreads) void k_morton(const float4 *__restrict__ leaf_lo,
                                                      const float4 *__restrict__ leaf_hi, uint32_t n,
@@ -195,22 +192,35 @@ __global__ __launch_bounds__(kThreads) void k_morton(const float4 *__restrict__ 
   const float4 bl = leaf_lo[i], bh = leaf_hi[i];
   float c[3] = {0.5f * (bl.x + bh.x), 0.5f * (bl.y + bh.y), 0.5f * (bl.z + bh.z)};
   if (bl.w != 0.f) c[0] = c[1] = c[2] = 0.f;  // null leaf (empty box): any code will do
-  // one scale for all axes (cubic cells): a flat scene must not spend a third of its code
-  // bits slicing its thin axis
-  float lo[3], ext = 0.f;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    lo[k] = ord2f(cbounds[k]);
-    ext = fmaxf(ext, ord2f(cbounds[3 + k]) - lo[k]);
+  // The 30 code bits go, one at a time from the top, to the axis whose cells are the longest at
+  // that point (ties: x, then y, then z), each bit halving that axis's cells.  A cube-shaped scene
+  // gets the usual x y z x y z ... interleave, 10 bits per axis; a flat one -- a terrain -- spends
+  // its bits on the two axes it extends along (13 + 13 + 4 instead of 10 + 10 + 10 of which the
+  // thin axis uses 5), so the lowest levels of the tree still follow where the primitives are.
+  // A bit of an axis is the next binary digit of the centre's position along it (doubling a
+  // float in [0, 1) and taking off the 1 are exact).
+  float ex = ord2f(cbounds[3]) - ord2f(cbounds[0]), ey = ord2f(cbounds[4]) - ord2f(cbounds[1]),
+        ez = ord2f(cbounds[5]) - ord2f(cbounds[2]);
+#if !RT_MORTON_ADAPTIVE
+  ex = ey = ez = fmaxf(fmaxf(ex, ey), ez);  // cubic cells, 10 bits per axis
+#endif
+  const float top = 0x1.fffffep-1f;
+  float tx = ex > 0.f ? fminf(fmaxf((c[0] - ord2f(cbounds[0])) / ex, 0.f), top) : 0.f;
+  float ty = ey > 0.f ? fminf(fmaxf((c[1] - ord2f(cbounds[1])) / ey, 0.f), top) : 0.f;
+  float tz = ez > 0.f ? fminf(fmaxf((c[2] - ord2f(cbounds[2])) / ez, 0.f), top) : 0.f;
+  uint32_t key = 0;
+  for (int bit = 0; bit < 30; ++bit) {
+    uint32_t digit;
+    if (ex >= ey && ex >= ez) {
+      ex *= 0.5f; tx *= 2.f; digit = tx >= 1.f; tx -= (float)digit;
+    } else if (ey >= ez) {
+      ey *= 0.5f; ty *= 2.f; digit = ty >= 1.f; ty -= (float)digit;
+    } else {
+      ez *= 0.5f; tz *= 2.f; digit = tz >= 1.f; tz -= (float)digit;
+    }
+    key = (key << 1) | digit;
   }
-  uint32_t q[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float t = ext > 0.f ? (c[k] - lo[k]) / ext : 0.f;
-    t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
-    q[k] = (uint32_t)t;
-  }
-  keys[i] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+  keys[i] = key;
   vals[i] = i;
 }
 
