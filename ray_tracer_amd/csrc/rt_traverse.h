@@ -102,7 +102,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
   Closest<APPROX> C;
   C.reset(a);
   const f3 inv_d = mk3(slab_rcp(d.x), slab_rcp(d.y),
-                       __builtin_amdgcn_rcpf(d.z));
+                       slab_rcp(d.z));
   const f3 oi = mk3(o.x * inv_d.x, o.y * inv_d.y, o.z * inv_d.z);
   large_candidates<DIEL>(S, o, d, a, skip, C);
   if constexpr (COUNT) *n_prims += S.n_large;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised strict-mode parity runs: HIP kernels (through the C ABI) against the CPU oracle.
 
-    python tests/fuzz_parity.py [cases] [seed]        (FUZZ_BIG=1: larger images, ordered mixed launches with sparse waves;
+    python tests/fuzz_parity.py [cases] [seed] [first case]   (FUZZ_BIG=1: larger images, ordered mixed launches with sparse waves;
                                                        FUZZ_DEEP=1: thousands of primitives, brute force against LBVH)
 
 Not collected by pytest (a long-running hunt for rare mismatches, run by hand on a GPU box).
@@ -315,7 +315,8 @@ def main():
         return 0
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    for i in range(cases):
+    start = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    for i in range(start, cases):
         rng = np.random.default_rng([seed, i])
         c = random_case(rng)
         problems = run_case(c)

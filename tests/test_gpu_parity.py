@@ -394,6 +394,32 @@ def test_lbvh_rays_with_a_zero_direction_component(oracle, mode):
     assert np.array_equal(fast["ids"][:, w // 2], want["ids"][:, w // 2])
 
 
+@pytest.mark.parametrize("mode", [rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED, rt.MODE_WAVEFRONT])
+def test_lbvh_rays_with_a_zero_z_component(oracle, mode):
+    """The same for z: the camera is turned by a right angle about y with a view matrix of exact
+    zeros and ones, so the pixels of column w/2 look along (+-1, y, 0).  (tests/fuzz_parity.py found
+    such a ray, a bounce ray on a lattice scene, lost by the one-search-per-iteration tree search.)"""
+    import math
+    w, h = 64, 48
+    ubo = rt.make_ubo(w, h, 4, 4, yaw=math.pi / 2, diverge=0.0, defocus=40.0)
+    ubo[0:16] = np.rint(ubo[0:16])
+    ubo[38] = 0.37   # camera z: the rays of that column run in the plane z = 0.37
+    rng = np.random.default_rng(6)
+    sph = np.repeat(rt.default_scene()[:1], 48, axis=0).copy()
+    sph[:, 0:3] = rng.uniform(-3.0, 3.0, (48, 3))
+    sph[:24, 0] -= 7.0
+    sph[24:, 0] += 7.0
+    sph[:, 3] = rng.uniform(0.3, 0.9, 48)
+    want = oracle.render(ubo, sph, w, h)
+    assert (want["ids"][:, w // 2] >= 0).any()
+    got = gpu_render(ubo, sph, w, h, mode, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+    assert np.array_equal(got["ids"], want["ids"])
+    assert got["rays"] == want["rays"]
+    assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+    fast = gpu_render(ubo, sph, w, h, mode, rt.FLAG_FORCE_BVH)
+    assert np.array_equal(fast["ids"], want["ids"])
+
+
 def test_lbvh_finds_a_sphere_of_radius_zero(oracle):
     """The in-order loop hits a sphere of radius 0 with rays aimed at its centre (the discriminant
     comes out as +0 or as positive residue), so the tree search has to as well: its leaf box is sized
