@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised strict-mode parity runs: HIP kernels (through the C ABI) against the CPU oracle.
 
-    python tests/fuzz_parity.py [cases] [seed] [first case]   (FUZZ_BIG=1: larger images, ordered mixed launches with sparse waves;
+    python tests/fuzz_parity.py [cases] [seed] [first case]   (FUZZ_SECONDS=N: stop cleanly after N seconds; FUZZ_BIG=1: larger images, ordered mixed launches with sparse waves;
                                                        FUZZ_DEEP=1: thousands of primitives, brute force against LBVH)
 
 Not collected by pytest (a long-running hunt for rare mismatches, run by hand on a GPU box).
@@ -298,10 +298,15 @@ def run_deep(c):
 
 
 def main():
+    import time
+    deadline = time.monotonic() + float(os.environ.get("FUZZ_SECONDS", "1e9"))   # a run ends cleanly at its time budget
     if os.environ.get("FUZZ_DEEP"):
         cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
         seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
         for i in range(cases):
+            if time.monotonic() > deadline:
+                print(f"time budget reached after {i} deep cases, no mismatch", flush=True)
+                return 0
             c = deep_case(np.random.default_rng([seed, i, 77]))
             problems, height = run_deep(c)
             tag = (f"deep case {i} (seed {seed}): {c['w']}x{c['h']} spheres {c['sph'].shape[0]} {c['kind']} "
@@ -317,6 +322,9 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     start = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     for i in range(start, cases):
+        if time.monotonic() > deadline:
+            print(f"time budget reached after case {i - 1}, no mismatch", flush=True)
+            return 0
         rng = np.random.default_rng([seed, i])
         c = random_case(rng)
         problems = run_case(c)
