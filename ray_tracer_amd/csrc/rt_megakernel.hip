@@ -505,6 +505,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
   int skip = -1;
   Search<APPROX> Q;
   search_begin<DIEL>(S, o, d, skip, Q);
+  if (!active) Q.node = kSearchIdle;
 
   // The tile's cost for the next launch's order is the number of steps the wave took, not the
   // segments of its slowest pixel: with a tree the time of a wave follows the nodes its rays
@@ -514,9 +515,14 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
   uint32_t steps = 0;
   while (true) {
     steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)steps) + 1u;  // (wave-uniform: kept in a scalar register)
-    const bool want_inner = active && Q.node >= 0;
-    const bool want_shade = active && Q.node == kSearchOver;
-    const bool want_leaf = active && !want_inner && !want_shade;
+    // A lane without work holds kSearchIdle as its node, so each of the three votes is ONE
+    // vector compare of the node word: with a separate "active" flag and-ed into them the
+    // compiler materialised every vote as a select plus a second compare (12 instructions of
+    // ~30 at the head of every iteration; 4K glass batch 132.4 -> 129.6 ms, terrain frame
+    // 3.73 -> 3.68 ms).
+    const bool want_inner = Q.node >= 0;
+    const bool want_shade = Q.node == kSearchOver;
+    const bool want_leaf = (uint32_t)Q.node >= kLeafRefLowest;
     const int n_inner = __builtin_popcountll(__ballot(want_inner));
     const int n_leaf = __builtin_popcountll(__ballot(want_leaf));
     const int n_shade = __builtin_popcountll(__ballot(want_shade));
@@ -579,6 +585,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
         }
       }
       if (active) search_begin<DIEL>(S, o, d, skip, Q);
+      else Q.node = kSearchIdle;
     }
   }
   tally_wave<PROBE>(O, tile, nrays, steps);

@@ -183,6 +183,11 @@ __device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stac
 #endif
 
 constexpr int kSearchOver = (int)kNullLeaf;  // never a real child reference
+// a lane that has no search at all (k_mega_sched: its pixel is finished or outside the image);
+// leaf references are ~x with x < 2^30, i.e. the unsigned words from kLeafRefLowest up
+constexpr int kSearchIdle = (int)kNullLeaf + 1;
+constexpr uint32_t kLeafRefLowest = 0xC0000000u;
+static_assert(kLeafCountShift + 3 <= 30 && RT_LEAF_MAX_PRIMS <= 8, "leaf references must stay above kLeafRefLowest");
 
 template <bool APPROX>
 struct Search {
