@@ -222,6 +222,18 @@ __device__ __forceinline__ void end_frame(const Params &P, const Outputs &O, siz
 // tiles with the longest chains, which set the launch time) and the batched loop for the rest
 // (whose job is throughput).
 constexpr int kRegenPlain = 0, kRegenBatched = 1, kRegenMixed = 2;
+// Lanes of the wave for which p holds, as a 32-bit scalar.  (The count is taken by the instruction
+// itself: from __builtin_popcountll the compiler carried a 64-bit count into the comparisons that
+// follow, and 64-bit ordered compares exist only in the vector unit.)
+__device__ __forceinline__ int wave_count(bool p) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+  int n;
+  asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+  return n;
+}
+#ifndef RT_BATCH_VOTES
+#define RT_BATCH_VOTES 1
+#endif
 #ifndef RT_SPARSE_RANKS
 #define RT_SPARSE_RANKS 2
 #endif
@@ -311,6 +323,65 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
       if constexpr (SHADE_BATCH > 1) {
         // Hits wait too: the surface code runs once SHADE_BATCH lanes have one pending,
         // instead of after every search for the third of the lanes that hit.
+#if RT_BATCH_VOTES
+        // Every vote of this loop is ONE vector compare of a per-lane word: "has a hit pending"
+        // is pending.idx >= 0 and "has a path to end" is ended > 0, a lane that is finished
+        // holding ended = -1 (with bool flags and-ed together the compiler kept them as masks in
+        // scalar registers, updated by three scalar instructions at every divergent assignment,
+        // and materialised each vote as a select plus a second compare).
+        Hit pending;
+        pending.idx = -1;
+        pending.dst = 0.0f;
+        pending.cx = pending.cy = pending.cz = 0.0f;
+        while (true) {
+          if (ended == 0 && pending.idx < 0) {
+            const Hit h = closest_hit<BVH, APPROX, false, DIEL>(S, o, d, stack, skip);
+            ++nrays;
+            RT_STORE_FIRST_ID(h.idx);
+            if (h.idx >= 0) pending = h;
+            else ended = 1;
+          }
+          const int n_hit = wave_count(pending.idx >= 0);
+          const int n_ended = wave_count(ended > 0);
+          if (n_hit + n_ended == 0) break;
+          // a step runs when its batch is together; when neither is, the one more lanes wait for
+          // (the two conditions are written out as scalar tests: as bool variables they went
+          // through vector registers)
+          if (n_hit >= SHADE_BATCH || (n_ended < END_BATCH && n_hit >= n_ended)) {
+            if (pending.idx >= 0) {
+              skip = shade_hit<STRICT, EXT, APPROX>(S, pending, skip, rng, o, d, light, colour);
+              pending.idx = -1;
+              ++b;
+              if (b >= P.n_bounce) ended = 2;
+            }
+          }
+          if (!(n_ended >= END_BATCH || (n_hit < SHADE_BATCH && n_hit < n_ended))) continue;
+          if (ended > 0) {
+            if (ended == 1) light = fma3v(environment<STRICT>(P, d), colour, light);
+            ended = 0;
+            total = total + light;
+            ++s;
+            if (s >= P.n_spp) {
+              end_frame<PROBE>(P, O, (size_t)py * P.width + px, total, (float)(F.first + fi * F.stride));
+              ++fi;
+              if (fi >= F.count) {
+                ended = -1;
+              } else {
+                rng = pixel_seed(P, px, py, F.first + fi * F.stride);
+                total = mk3(0.f, 0.f, 0.f);
+                s = 0;
+              }
+            }
+            if (ended == 0) {
+              sample_ray<STRICT>(P, base, rng, o, d);
+              light = mk3(0.f, 0.f, 0.f);
+              colour = mk3(1.f, 1.f, 1.f);
+              b = 0;
+              skip = -1;
+            }
+          }
+        }
+#else
         Hit pending;
         pending.idx = -1;
         pending.dst = 0.0f;
@@ -347,6 +418,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
           if (!run_end) continue;
           RT_END_PATHS();
         }
+#endif
       } else {
         while (true) {
           if (active && ended == 0) {
