@@ -231,6 +231,15 @@ __device__ __forceinline__ int wave_count(bool p) {
   asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
   return n;
 }
+// Spheres fetched four per 64-byte scalar load in the batched loop of launches that are batched
+// throughout (the loop bookkeeping and the address arithmetic of the one-sphere-ahead fetch are
+// ~12 scalar instructions per sphere, and a wave's scalar instructions cost what its vector ones
+// do): 3840x2160 3.80 -> 3.69 ms, 2560x1440 1.722 -> 1.673 ms, 8K textured batch 219.7 -> 212.5 ms.
+// Not in the mixed kernel: there the larger loop costs the chain tiles 4 % (1920x1080 1.063 ->
+// 1.106 ms).
+#ifndef RT_BATCH_GROUPED
+#define RT_BATCH_GROUPED 1
+#endif
 #ifndef RT_BATCH_VOTES
 #define RT_BATCH_VOTES 1
 #endif
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
   // tiles just below the chain ranks still have long chains that large batches stretch; since the
   // heaviest tiles run as sparse waves, large batches for everything else win: 1920x1080 1.156 ->
   // 1.117 ms, and 1.105 with a chain share of 1/128 instead of 1/32.)
+  constexpr bool kGroupedFetch = RT_BATCH_GROUPED != 0 && FORM == kRegenBatched && !BVH;
   constexpr int SHADE_BATCH = FORM != kRegenPlain ? RT_REGEN_SHADE_BATCH : 1;
   constexpr int END_BATCH = FORM != kRegenPlain ? RT_REGEN_END_BATCH : 8;
   constexpr int BLOCK = BVH ? 256 : kTileBlock;
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
         pending.cx = pending.cy = pending.cz = 0.0f;
         while (true) {
           if (ended == 0 && pending.idx < 0) {
-            const Hit h = closest_hit<BVH, APPROX, false, DIEL>(S, o, d, stack, skip);
+            const Hit h = closest_hit<BVH, APPROX, kGroupedFetch, DIEL>(S, o, d, stack, skip);
             ++nrays;
             RT_STORE_FIRST_ID(h.idx);
             if (h.idx >= 0) pending = h;
