@@ -409,7 +409,8 @@ static inline v3 v_cross(v3 a, v3 b) {
  *   e1 = v1-v0, e2 = v2-v0, p = d x e2, det = e1.p          (det == 0: parallel, miss)
  *   tv = o-v0, un = tv.p, q = tv x e1, vn = d.q, tn = e2.q
  *   with s = sign(det): s*un >= 0, s*vn >= 0, s*(un+vn) <= s*det, s*tn >= 0   else miss
- *   det*det > 2^-40 (e1.e1)(p.p)   else miss (the ray runs in the triangle's plane)
+ *   det*det > 2^-40 (e1.e1)(p.p) and det*det > 2^-40 (d.d)(n.n), n = e1 x e2
+ *                                  else miss (the ray runs in the triangle's plane)
  *   dst = tn / det;  point = o + d*dst;  normal = normalize(e1 x e2), turned against d
  * Both faces are hit.  A triangle without area -- e1 x e2 == (0, 0, 0) as computed by v_cross, which
  * covers two equal vertices and collinear lattice points -- is never hit: the sign tests above
@@ -434,6 +435,13 @@ static inline hit_t ray_triangle(v3 o, v3 d, v3 v0, v3 v1, v3 v2) {
    * below 2^-20): det is then rounding residue, and so is everything divided by it.  Tested last,
    * so only a candidate that would otherwise be accepted pays for it. */
   if (!(det * det > 0x1p-40f * (v_dot(e1, e1) * v_dot(p, p)))) return h;
+  /* The same angle measured against the plane's own normal: when the ray also runs nearly along
+   * the edge e2 (a camera on the extension of that edge), p = d x e2 is itself a small difference
+   * of large products, and the residue in det is no longer small beside |e1| |p|. */
+  {
+    v3 nn = v_cross(e1, e2);
+    if (!(det * det > 0x1p-40f * (v_dot(d, d) * v_dot(nn, nn)))) return h;
+  }
   h.hit = 1;
   h.dst = tn / det;
   h.point = v_fma(d, h.dst, o);

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
 #ifdef RT_MEASURE_TIMELINE
   const unsigned long long t_begin_sched = wall_clock64();
 #endif
-  bool active = px < P.width && py < P.height && F.count;
+  const bool active = px < P.width && py < P.height && F.count;
   const f3 base = pixel_direction(P, px, py);
   constexpr bool kIdsEarly = true;
   int id0 = -1;  // (unused here: RT_STORE_FIRST_ID stores at once)
@@ -644,6 +644,10 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
         light = fma3v(environment<STRICT>(P, d), colour, light);
         path_done = true;
       }
+      // (whether the pixel goes on is a flag of this step only; between steps a finished lane is
+      // known by its node word, kSearchIdle: a flag carried around the loop is a scalar mask that
+      // costs three scalar instructions in every iteration)
+      bool more = true;
       if (path_done) {
         total = total + light;
         ++s;
@@ -651,14 +655,14 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
           end_frame<PROBE>(P, O, (size_t)py * P.width + px, total, (float)(F.first + fi * F.stride));
           ++fi;
           if (fi >= F.count) {
-            active = false;
+            more = false;
           } else {
             rng = pixel_seed(P, px, py, F.first + fi * F.stride);
             total = mk3(0.f, 0.f, 0.f);
             s = 0;
           }
         }
-        if (active) {
+        if (more) {
           sample_ray<STRICT>(P, base, rng, o, d);
           light = mk3(0.f, 0.f, 0.f);
           colour = mk3(1.f, 1.f, 1.f);
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(kTileBlock, STRICT ? 1 : (EXT ? RT_SCHED_EXT_WAVES 
           skip = -1;
         }
       }
-      if (active) search_begin<DIEL>(S, o, d, skip, Q);
+      if (more) search_begin<DIEL>(S, o, d, skip, Q);
       else Q.node = kSearchIdle;
     }
   }

@@ -135,6 +135,12 @@ __device__ __forceinline__ void triangle_candidate(const float4 *__restrict__ T,
   // a ray that runs in the triangle's plane to within rounding: det is residue (tested last, so
   // only a candidate that would otherwise be accepted pays for it)
   if (!(det * det > 0x1p-40f * (dot(e1, e1) * dot(p, p)))) return;
+  // the same angle against the plane's own normal: for a ray that also runs nearly along e2, p is
+  // a small difference of large products and the residue in det is not small beside |e1| |p|
+  {
+    const f3 nn = cross(e1, e2);
+    if (!(det * det > 0x1p-40f * (dot(d, d) * dot(nn, nn)))) return;
+  }
   const float t = ieee_div(tn, det);
   if (t < best.dst || (t == best.dst && idx < best.idx)) {
     best.dst = t;

@@ -650,6 +650,34 @@ def test_rays_in_the_plane_of_a_triangle_miss_it(oracle, accel):
     assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
 
 
+@pytest.mark.parametrize("accel", [rt.FLAG_FORCE_BRUTE, rt.FLAG_FORCE_BVH])
+def test_rays_along_an_edge_in_the_plane_of_a_triangle_miss_it(oracle, accel):
+    """The camera on the extension of a triangle's edge (v0 = 5/3 v2, both on a line through the
+    origin): rays towards v2 run in the triangle's plane AND nearly along e2, so p = d x e2 is a small
+    difference of large products and the residue in det is not small beside |e1| |p|; the in-plane
+    rule measured against |e1| |p| alone let the in-order loop report a hit at distance 0 that the
+    tree search does not see.  The rule also measures det against |d| |e1 x e2|.  (Found by
+    tests/fuzz_parity.py, seed 61 case 1100: pixel (69, 79) saw the triangle instead of the sphere
+    centred on v2.)"""
+    w, h = 82, 107
+    ubo = rt.make_ubo(w, h, 5, 2, diverge=0.0)
+    sph = rt.default_scene()[:2].copy()
+    sph[0, :4] = (0, -1000.5, 0, 1000)
+    sph[1, :4] = (3, 3, -6, 1)
+    v = np.array([[5, 5, -10], [2, 6, -8], [3, 3, -6],          # n = (8, 8, 8), n . v0 = 0: through the origin
+                  [-3, -3, -7], [3, -3, -7], [0, 3, -7]], dtype=np.float32)
+    t = np.array([[0, 1, 2], [3, 4, 5]], dtype=np.uint32)
+    mat = rt.matte(0.7, 0.6, 0.4, smoothness=0.5, specular_probability=0.5)
+    want = oracle.render(ubo, sph, w, h, 552, 1, 1, mesh=(v, t, mat))
+    ids = want["ids"].reshape(h, w)
+    assert not (ids == 2).any() and ids[79, 69] == 1
+    for mode in (rt.MODE_MEGAKERNEL, rt.MODE_MEGAKERNEL_NESTED):
+        got = gpu_render_mesh(ubo, sph, (v, t, mat), w, h, mode, rt.FLAG_STRICT_MATH | accel, 552, 1, 1)
+        assert np.array_equal(got["ids"], want["ids"])
+        assert got["rays"] == want["rays"]
+        assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
+
+
 def test_mesh_only_scene_and_removal(oracle):
     w, h = 96, 64
     ubo = rt.make_ubo(w, h, 1, 4)
