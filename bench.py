@@ -121,19 +121,61 @@ def cpu_baseline(wl, scene, threads: int):
     }
 
 
+def source_fingerprint() -> str:
+    """sha256 over the kernel sources (ray_tracer_amd/csrc/*.hip, *.h, in name order): what ties a
+    committed counter pass to the code it was taken on, independent of commits that touch no kernel."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "ray_tracer_amd", "csrc")
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            with open(os.path.join(src, fn), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_entry(config: int):
     """Counter figures of the benchmarked kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_latest.json; FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE).
-    bench.py cannot collect hardware counters itself; {} if no profile is committed."""
+    bench.py cannot collect hardware counters itself; {} if no profile is committed.  The entry
+    carries the fingerprint of the kernel sources the passes were taken on; `traffic_stale` in the
+    printed line says whether the sources have changed since."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        if "configs" in d:
-            return d["configs"].get(str(config), {})
-        return d if config == 1 else {}
+        e = dict(d["configs"].get(str(config), {})) if "configs" in d else (dict(d) if config == 1 else {})
+        if e:
+            e["source_sha"] = d.get("source_sha")
+            e["commit"] = d.get("commit")
+            e["load_latency_cycles"] = d.get("load_latency_cycles")
+            now = source_fingerprint()
+            e["stale"] = None if d.get("source_sha") is None else (d.get("source_sha") != now)
+            e["source_sha_now"] = now
+        return e
     except Exception:
         return {}
+
+
+def traffic_stamp(pmc) -> dict:
+    """The fields that say where `traffic` and the counter ratios come from."""
+    if not pmc:
+        return {"traffic_source": None}
+    out = {"traffic_source": pmc.get("source"), "traffic_commit": pmc.get("commit"),
+           "traffic_source_sha": pmc.get("source_sha"), "source_sha_now": pmc.get("source_sha_now"),
+           "traffic_stale": pmc.get("stale")}
+    if pmc.get("stale"):
+        out["warning"] = ("the kernel sources have changed since the committed counter passes were taken: "
+                          "traffic and the counter ratios describe the earlier kernels (re-run tools/profile_configs.sh)")
+    return out
+
+
+def lbvh_algorithmic_build_bytes(n_prims: int, prim_bytes: int) -> float:
+    """Bytes an LBVH build of n primitives has to move: read each primitive, write its box (24 B), write and
+    then sort an 8-byte (code, index) pair through four 8-bit radix passes (read + write per pass), write
+    n - 1 nodes of 64 bytes (both child boxes inline)."""
+    return n_prims * (prim_bytes + 24.0 + 8.0 * (1 + 2 * 4)) + max(n_prims - 1, 0) * 64.0
 
 
 def build_scene(rt, np, wl):
@@ -345,6 +387,55 @@ def main() -> None:
                 s = x.stats()
                 nodes_per_seg = s.bvh_nodes_visited / max(s.rays, 1)
                 prims_per_seg = s.bvh_spheres_tested / max(s.rays, 1)
+    # the LBVH build on a device that does nothing else (HIP events around the build's own kernels)
+    build_block = None
+    if wl["scene"] in ("grid", "terrain") and args.mode == "megakernel" and not args.no_side_runs:
+        with rt.Renderer(WIDTH, HEIGHT, device=local_rank) as x:
+            apply_scene(x, rt, scene)
+            t = [x.stats().last_build_ms]
+            for k in range(6):
+                if terrain is not None:
+                    v = terrain["verts"][k % len(terrain["verts"])]
+                    x.set_mesh_device(v.data_ptr(), terrain["n_v"], terrain["idx"].data_ptr(), terrain["n_t"],
+                                      terrain["mat"])
+                else:
+                    x.set_spheres(scene["spheres"])
+                    if scene["ior"] is not None:
+                        x.set_dielectric(scene["ior"])
+                x.sync()
+                t.append(x.stats().last_build_ms)
+            t = sorted(t[1:])
+            n_prims = n_spheres + (terrain["n_t"] if terrain is not None else 0)
+            prim_bytes = 36 if terrain is not None else 16
+            ms = t[len(t) // 2]
+            alg = lbvh_algorithmic_build_bytes(n_prims, prim_bytes)
+            build_block = {"ms": ms, "ms_min": t[0], "primitives": n_prims, "mprims_per_s": n_prims / ms / 1e3,
+                           "algorithmic_bytes": alg, "gb_per_s": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / PEAK_HBM_GBS,
+                           "height": x.stats().bvh_height,
+                           "how": "median of 6 rebuilds on an otherwise idle device, HIP events around the build's kernels"}
+    # the reduce on its own: one accumulation image summed onto rank 0, nothing else running
+    reduce_block = None
+    if world > 1:
+        probe_img = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+        times = []
+        for k in range(6):
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0r = time.perf_counter()
+            end_sum(begin_sum(probe_img))
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - t0r)
+        tr = torch.tensor([sorted(times[1:])[2]], dtype=torch.float64, device=small)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        nbytes = HEIGHT * WIDTH * 16
+        peak = 7 * 153.0
+        reduce_block = {"bytes_per_rank": nbytes, "ms": float(tr.item()) * 1e3,
+                        "gb_per_s_into_root": (world - 1) * nbytes / float(tr.item()) / 1e9,
+                        "peak_GBs": peak, "frac": (world - 1) * nbytes / float(tr.item()) / 1e9 / peak,
+                        "how": "median of 5 stand-alone reduces of one W x H float4 image (max over ranks); the root "
+                               "receives (N - 1) images over its 7 xGMI links of ~153 GB/s each; in the timed steps the "
+                               "reduce of step i runs beside the trace of step i + 1"}
+        del probe_img
     for i in range(args.warmup):
         step(i)
     fence()
@@ -407,7 +498,7 @@ def main() -> None:
             cfg["wavefront_ms_per_frame_1080p_64spp"] = other_ms
             cfg["strict_ms_per_frame"] = strict_ms
         if terrain is not None:
-            cfg["lbvh_build_ms"] = st_last.last_build_ms
+            cfg["lbvh_build_ms_in_flight"] = st_last.last_build_ms   # beside another frame's trace; lbvh_build.ms is the build alone
             cfg["trace_ms"] = launch_ms
             cfg["lbvh_height"] = st_last.bvh_height
             cfg["frames_in_flight"] = n_buf
@@ -431,26 +522,58 @@ def main() -> None:
                 achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
             else:
                 alg_bytes, achieved = None, None
+            launch_s = launch_ms * 1e-3
+            # three resources, each as a fraction of its own peak; the largest one governs
+            hbm_bytes = pmc.get("hbm_bytes_per_launch")
+            hbm_frac = hbm_bytes / launch_s / 1e9 / PEAK_HBM_GBS if hbm_bytes and launch_s > 0 else None
+            l2_bytes = pmc.get("l1_to_l2_bytes_per_launch")
+            l2_frac = l2_bytes / launch_s / 1e9 / PEAK_L2_GBS if l2_bytes and launch_s > 0 else None
+            lat = pmc.get("load_latency_cycles") or {}
+            lat_frac = lat_ms = lat_avg = None
+            if nodes_per_seg is not None and lat and pmc.get("l1_hit_rate") is not None and \
+                    pmc.get("waves_per_simd") and pmc.get("valu_lane_utilisation"):
+                l1, l2h = pmc["l1_hit_rate"], pmc.get("l2_hit_rate", 1.0)
+                lat_avg = l1 * lat["l1_16KB"] + (1 - l1) * (l2h * lat["l2_1MB"] + (1 - l2h) * lat["mall_64MB"])
+                fetches = (rays / steps) * (nodes_per_seg + prims_per_seg)
+                lanes = 1024 * pmc["waves_per_simd"] * 64 * pmc["valu_lane_utilisation"]
+                lat_ms = fetches * lat_avg / lanes / 2.4e9 * 1e3
+                lat_frac = lat_ms / launch_ms if launch_ms > 0 else None
+            cands = [(f, n) for f, n in ((hbm_frac, "hbm"), (l2_frac, "l2"), (lat_frac, "latency")) if f is not None]
+            governing = max(cands)[1] if cands else "hbm"
+            frac = dict((n, f) for f, n in cands).get(governing)
             roof = {
-                "bound": "hbm",
+                "bound": governing,
                 "kernel": kernel,
-                "achieved": achieved,
-                "peak": PEAK_HBM_GBS,
-                "unit": "GB/s",
-                "frac": achieved / PEAK_HBM_GBS if achieved is not None else None,
-                "traffic": pmc.get("hbm_bytes_per_launch"),
-                "traffic_source": pmc.get("source"),
+                "frac": frac,
+                "achieved": {"hbm": (hbm_bytes or 0) / launch_s / 1e9 if launch_s > 0 else None,
+                             "l2": (l2_bytes or 0) / launch_s / 1e9 if launch_s > 0 else None,
+                             "latency": lat_ms}.get(governing),
+                "peak": {"hbm": PEAK_HBM_GBS, "l2": PEAK_L2_GBS, "latency": launch_ms}.get(governing),
+                "unit": {"hbm": "GB/s", "l2": "GB/s", "latency": "ms (model of dependent fetches / measured launch)"}.get(governing),
+                "traffic": hbm_bytes,
+                **traffic_stamp(pmc),
                 "launch_ms": launch_ms,
+                "frac_hbm": hbm_frac,
+                "frac_l2": l2_frac,
+                "frac_latency": lat_frac,
+                "l1_to_l2_bytes_per_launch": l2_bytes,
+                "latency_model": {
+                    "ms": lat_ms, "mean_load_latency_cycles": lat_avg, "load_latency_cycles": lat or None,
+                    "what": "segments x (nodes + primitives fetched per segment, tallied live) x mean dependent-load "
+                            "latency (idle-chip pointer chase, tools/micro/load_latency.hip, weighted by the counter "
+                            "passes' L1 / L2 hit rates) / (1024 SIMDs x resident waves x 64 lanes x share of lanes active) "
+                            "at 2.4 GHz: the time the launch needs if every active lane keeps exactly one fetch in flight"},
+                # the rate at which the search consumes node and primitive bytes, served by L1 / L2: NOT a share of HBM
+                "achieved_cached_gb_per_s": achieved,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_segment": bytes_per_segment,
                 "nodes_per_segment": nodes_per_seg,
                 "primitives_tested_per_segment": prims_per_seg,
-                "frac_of_l2_peak": achieved / PEAK_L2_GBS if achieved is not None else None,
-                "binds": "neither bandwidth: the tree's working set is served from L1/L2 and the launch waits on the "
-                         "latency of dependent node fetches; see valu_instructions_per_simd_cycle and "
-                         "valu_lane_utilisation (committed counter passes)",
                 "valu_instructions_per_simd_cycle": pmc.get("valu_instructions_per_simd_cycle"),
+                "valu_issue_frac_of_hw_rate": pmc.get("valu_issue_frac_of_hw_rate"),
                 "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
+                "waves_per_simd": pmc.get("waves_per_simd"),
+                "l1_hit_rate": pmc.get("l1_hit_rate"),
                 "l2_hit_rate": pmc.get("l2_hit_rate"),
             }
         else:
@@ -467,10 +590,14 @@ def main() -> None:
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                 "traffic": pmc.get("hbm_bytes_per_launch"),
-                "traffic_source": pmc.get("source"),
-                # from the same committed counter passes: wave-level VALU instructions per SIMD-cycle
-                # over what a SIMD was measured to issue, and share of the 64 lanes active per instruction
-                "valu_issue_frac": pmc.get("valu_issue_frac"),
+                **traffic_stamp(pmc),
+                # from the same committed counter passes: wave-level VALU instructions per SIMD-cycle over the
+                # hardware rate (a wave64 VALU instruction occupies a SIMD-32 for 2 cycles: 0.5 per cycle), over
+                # what a SIMD was measured to issue for independent adds (0.40, tools/micro/issue_cost.hip), and
+                # the share of the 64 lanes active per instruction
+                "valu_instructions_per_simd_cycle": pmc.get("valu_instructions_per_simd_cycle"),
+                "valu_issue_frac_of_hw_rate": pmc.get("valu_issue_frac_of_hw_rate"),
+                "valu_issue_frac_of_measured_ceiling": pmc.get("valu_issue_frac"),
                 "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
                 "launch_ms": launch_ms,
                 "algorithmic_flops_per_launch": flops,
@@ -492,6 +619,10 @@ def main() -> None:
             "config": cfg,
             "roofline": roof,
         }
+        if build_block is not None:
+            out["lbvh_build"] = build_block
+        if reduce_block is not None:
+            out["reduce"] = reduce_block
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(wl, scene, threads)

@@ -44,6 +44,7 @@ void usage() {
       "  --device D                  HIP device ordinal (with --gpus: the first of N consecutive ones)\n"
       "  --gpus N                    split the frames over N devices and sum the images with one RCCL reduce\n"
       "  --reduce                    take the multi-device path (threads, RCCL communicator, reduce, resolve) even for N = 1\n"
+      "  --fail-rank R               fault injection: device R of the multi-device path reports a failed render\n"
       "  --out FILE.ppm|FILE.png     shown as the reference's window shows it (bottom row first in memory)\n");
 }
 
@@ -58,7 +59,7 @@ int die(const char *what) {
 
 int main(int argc, char **argv) {
   uint32_t width = 800, height = 608, frames = 1, mode = RT_MODE_MEGAKERNEL, flags = 0;
-  int device = 0, gpus = 1;
+  int device = 0, gpus = 1, fail_rank = -1;
   bool viewport_image = true, always_reduce = false;
   std::string scene = "default", out_path, mesh_path, texture_name;
   long tex_first = -1, tex_count = 1;
@@ -111,6 +112,7 @@ int main(int argc, char **argv) {
     else if (a == "--device") device = std::atoi(next());
     else if (a == "--gpus") gpus = std::atoi(next());
     else if (a == "--reduce") always_reduce = true;
+    else if (a == "--fail-rank") fail_rank = std::atoi(next());
     else if (a == "--out") out_path = next();
     else { usage(); return a == "--help" || a == "-h" ? 0 : 2; }
   }
@@ -213,6 +215,7 @@ int main(int argc, char **argv) {
   std::vector<rt_stats> st((size_t)gpus);
   std::vector<std::string> failure((size_t)gpus);
   double wall_ms = 0.0;
+  size_t reduce_bytes = 0;   // bytes each non-root device contributes to the sum
   if (gpus == 1 && !always_reduce) {
     if (const char *what = make_context(device, nullptr, &ctx[0])) return die(what);
     const auto t0 = std::chrono::steady_clock::now();
@@ -234,44 +237,70 @@ int main(int argc, char **argv) {
       return 1;
     }
     std::vector<hipStream_t> stream((size_t)gpus, nullptr);
+    // every way out of this branch that is not success goes through here: communicators that may have a
+    // collective outstanding are aborted, not destroyed (destroy would wait for peers that never arrive)
+    auto give_up = [&]() {
+      for (int r = 0; r < gpus; ++r) ncclCommAbort(comm[(size_t)r]);
+      for (int r = 0; r < gpus; ++r)
+        if (ctx[(size_t)r]) rt_destroy(ctx[(size_t)r]);
+      return 1;
+    };
     for (int r = 0; r < gpus; ++r) {
       if (hipSetDevice(devs[(size_t)r]) != hipSuccess || hipStreamCreate(&stream[(size_t)r]) != hipSuccess) {
         std::fprintf(stderr, "rt_headless: cannot create a stream on device %d\n", devs[(size_t)r]);
-        return 1;
+        return give_up();
       }
-      if (const char *what = make_context(devs[(size_t)r], stream[(size_t)r], &ctx[(size_t)r])) return die(what);
+      if (const char *what = make_context(devs[(size_t)r], stream[(size_t)r], &ctx[(size_t)r])) {
+        die(what);
+        return give_up();
+      }
     }
-    // rt_last_error is per thread: a rank keeps its own message
+    // Phase 1, one host thread per device: trace this device's share of the frames.  No collective is
+    // enqueued here, so a rank that fails cannot leave its peers waiting inside one.  A context is only
+    // ever touched by its own thread (rt_last_error is per thread: a rank keeps its own message).
+    std::vector<void *> accum((size_t)gpus, nullptr);
+    size_t bytes = 0;
+    std::vector<size_t> rank_bytes((size_t)gpus, 0);
     auto rank_main = [&](int r) {
       const size_t k = (size_t)r;
       auto fail_with = [&](const char *what) { failure[k] = std::string(what) + ": " + rt_last_error(); };
+      if (hipSetDevice(devs[k]) != hipSuccess) { failure[k] = "hipSetDevice failed"; return; }
       if (const char *what = render_frames(ctx[k], (uint32_t)r, (uint32_t)gpus)) { fail_with(what); return; }
-      void *accum = nullptr, *root = nullptr;
-      size_t bytes = 0;
-      if (rt_accum_device_ptr(ctx[k], &accum, &bytes) != RT_OK || rt_accum_device_ptr(ctx[0], &root, nullptr) != RT_OK) {
-        fail_with("rt_accum_device_ptr");
-        return;
-      }
-      // ordered behind this rank's render launches on the same stream; in place on the root
-      if (ncclReduce(accum, r == 0 ? accum : nullptr, bytes / sizeof(float), ncclFloat, ncclSum, 0, comm[k],
-                     stream[k]) != ncclSuccess) {
-        failure[k] = "ncclReduce failed";
-        return;
-      }
-      if (r == 0 && rt_resolve(ctx[0]) != RT_OK) { fail_with("rt_resolve"); return; }
-      if (rt_sync(ctx[k]) != RT_OK) { fail_with("rt_sync"); return; }
-      if (rt_get_stats(ctx[k], &st[k]) != RT_OK) fail_with("rt_get_stats");
+      if (r == fail_rank) { failure[k] = "rt_render: injected failure (--fail-rank)"; return; }
+      if (rt_accum_device_ptr(ctx[k], &accum[k], &rank_bytes[k]) != RT_OK) fail_with("rt_accum_device_ptr");
     };
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> threads;
-    for (int r = 0; r < gpus; ++r) threads.emplace_back(rank_main, r);
-    for (auto &t : threads) t.join();
-    wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    {
+      std::vector<std::thread> threads;
+      for (int r = 0; r < gpus; ++r) threads.emplace_back(rank_main, r);
+      for (auto &t : threads) t.join();
+    }
+    bool failed = false;
     for (int r = 0; r < gpus; ++r)
       if (!failure[(size_t)r].empty()) {
         std::fprintf(stderr, "rt_headless: device %d: %s\n", devs[(size_t)r], failure[(size_t)r].c_str());
-        return 1;
+        failed = true;
       }
+    if (failed) return give_up();
+    bytes = rank_bytes[0];
+    // Phase 2, only when every rank has its image: ONE sum onto device 0, each rank's part enqueued on the
+    // stream its render launches went to (so it runs behind them without a host wait), in place on the root.
+    ncclResult_t nrc = ncclGroupStart();
+    for (int r = 0; r < gpus && nrc == ncclSuccess; ++r)
+      nrc = ncclReduce(accum[(size_t)r], r == 0 ? accum[0] : nullptr, bytes / sizeof(float), ncclFloat, ncclSum, 0,
+                       comm[(size_t)r], stream[(size_t)r]);
+    const ncclResult_t nend = ncclGroupEnd();
+    if (nrc != ncclSuccess || nend != ncclSuccess) {
+      std::fprintf(stderr, "rt_headless: ncclReduce failed: %s\n", ncclGetErrorString(nrc != ncclSuccess ? nrc : nend));
+      return give_up();
+    }
+    if (rt_resolve(ctx[0]) != RT_OK) { die("rt_resolve"); return give_up(); }
+    for (int r = 0; r < gpus; ++r) {
+      if (rt_sync(ctx[(size_t)r]) != RT_OK) { die("rt_sync"); return give_up(); }
+      if (rt_get_stats(ctx[(size_t)r], &st[(size_t)r]) != RT_OK) { die("rt_get_stats"); return give_up(); }
+    }
+    wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    reduce_bytes = gpus > 1 ? bytes : 0;
     for (int r = 0; r < gpus; ++r) ncclCommDestroy(comm[(size_t)r]);
   }
   rt_free(vertices);
@@ -295,9 +324,9 @@ int main(int argc, char **argv) {
   }
   std::printf("{\"width\": %u, \"height\": %u, \"frames\": %u, \"gpus\": %d, \"spheres\": %zu, \"triangles\": %u, "
               "\"rays\": %llu, \"device_ms\": %.3f, \"wall_ms\": %.3f, \"mrays_per_s\": %.1f, \"bvh_nodes\": %u, "
-              "\"bvh_build_ms\": %.3f, \"image_byte_sum\": %llu}\n",
+              "\"bvh_build_ms\": %.3f, \"reduce_bytes_per_device\": %zu, \"image_byte_sum\": %llu}\n",
               width, height, frames, gpus, spheres.size(), n_triangles, (unsigned long long)rays, device_ms, wall_ms,
-              device_ms > 0 ? rays / device_ms / 1e3 : 0.0, st[0].bvh_nodes, st[0].last_build_ms,
+              device_ms > 0 ? rays / device_ms / 1e3 : 0.0, st[0].bvh_nodes, st[0].last_build_ms, reduce_bytes,
               (unsigned long long)sum);
   for (int r = 0; r < gpus; ++r) rt_destroy(ctx[(size_t)r]);
   return 0;

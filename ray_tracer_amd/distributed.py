@@ -57,3 +57,30 @@ def finish_reduce(handle) -> None:
     block until it is done (gloo)."""
     if handle is not None:
         handle.wait()
+
+
+def render_split(renderer, accum, first_frame: int, n_frames: int, rank: int, world: int,
+                 stage_on_host: bool = False) -> None:
+    """One image over ``world`` ranks: this rank traces its share of the frames into ``accum`` (the
+    torch tensor the renderer was created on, ``accum_buffer=accum.data_ptr()``), the images are
+    summed onto rank 0, and rank 0 resolves the sum to its 8-bit image.  ``stage_on_host`` sums host
+    copies instead (gloo, for ranks that share one device: a rehearsal of the control flow, RCCL
+    needs one device per rank)."""
+    import torch
+    import torch.distributed as dist
+
+    first, count, stride = frame_partition(first_frame, n_frames, rank, world)
+    renderer.render(first, count, stride)
+    if world > 1:
+        if stage_on_host:
+            renderer.sync()
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                accum.copy_(host)
+                torch.cuda.synchronize(accum.device)
+        else:
+            finish_reduce(start_reduce(accum, dst=0))
+    if rank == 0:
+        renderer.resolve()
+    renderer.sync()

@@ -23,6 +23,7 @@ import sys
 
 src = sys.argv[1]
 ISSUE_CAPACITY = 0.40   # wave-level VALU instructions one SIMD issues per cycle (tools/micro/issue_cost.hip)
+HW_ISSUE_RATE = 0.5     # the hardware rate: a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
 
 
 def parse(path):
@@ -79,6 +80,7 @@ for c in ("0", "1", "2", "3", "4"):
             e["valu_instructions_per_simd_cycle"] = round(k["SQ_INSTS_VALU"] / (1024 * cycles), 4)
             e["valu_issue_capacity_per_simd_cycle"] = ISSUE_CAPACITY
             e["valu_issue_frac"] = round(k["SQ_INSTS_VALU"] / (1024 * cycles) / ISSUE_CAPACITY, 3)
+            e["valu_issue_frac_of_hw_rate"] = round(k["SQ_INSTS_VALU"] / (1024 * cycles) / HW_ISSUE_RATE, 3)
         if "SQ_WAVE_CYCLES" in k:
             e["waves_per_simd"] = round(4 * k["SQ_WAVE_CYCLES"] / (1024 * cycles), 2)
     if "SQ_THREAD_CYCLES_VALU" in k and "SQ_ACTIVE_INST_VALU" in k:
@@ -89,6 +91,29 @@ for c in ("0", "1", "2", "3", "4"):
         e["l2_hit_rate"] = round(k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]), 3)
     if "TCP_TCC_READ_REQ_sum" in k and "TCP_TOTAL_CACHE_ACCESSES_sum" in k:
         e["l1_hit_rate"] = round(1 - k["TCP_TCC_READ_REQ_sum"] / k["TCP_TOTAL_CACHE_ACCESSES_sum"], 3)
+        # vector L1 -> L2 read requests, taken as 64 bytes each (the size FETCH_SIZE tallies requests at)
+        e["l1_to_l2_bytes_per_launch"] = int(k["TCP_TCC_READ_REQ_sum"] * 64)
+    for extra in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU_TRANS"):
+        if extra in k:
+            e[extra.lower() + "_per_launch"] = k[extra]
     out["configs"][c] = e
+# what ties these figures to the code they were measured on: the fingerprint of the kernel sources
+# (bench.py recomputes it and flags a mismatch) and the commit this file was built at
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import subprocess  # noqa: E402
+
+from bench import source_fingerprint  # noqa: E402
+
+out["source_sha"] = source_fingerprint()
+try:
+    out["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    out["commit"] = None
+lat = os.path.join(src, "load_latency.json")
+if os.path.exists(lat):
+    d = json.load(open(lat))
+    out["load_latency_cycles"] = {k: v for k, v in d.items() if isinstance(v, float)}
+    out["load_latency_source"] = f"{lat} (tools/micro/load_latency.hip: {d.get('unit')})"
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(src.rstrip("/"))), "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
