@@ -81,6 +81,10 @@ typedef struct rt_stats {
   uint32_t bvh_height;      /* longest root-to-leaf path of the LBVH, in edges */
   uint64_t bvh_nodes_visited;   /* with RT_FLAG_COUNT_TRAVERSAL: 64-byte node fetches */
   uint64_t bvh_spheres_tested;  /* with RT_FLAG_COUNT_TRAVERSAL: 16-byte sphere fetches */
+  uint32_t bvh_fallback;    /* 1: an LBVH was wanted and built but is taller than the traversal stack
+                               (64 levels), so the scene is traced by brute force -- correct, slow;
+                               bvh_nodes is 0 then as it is under RT_FLAG_FORCE_BRUTE */
+  uint32_t reserved;
 } rt_stats;
 
 /* Replaces createTexture(RGBA8_UNORM, W, H, STORAGE) + zero fill, main.cpp:393-448,
@@ -107,7 +111,14 @@ int rt_set_spheres(rt_ctx *ctx, const void *spheres64, uint32_t count);
  * Both faces are hit; the shading normal is the geometric normal turned against the ray.
  * A triangle without area (a repeated vertex, collinear vertices whose edge cross product is
  * exactly zero) keeps its id but is never hit.
- * n_triangles = 0 removes the mesh.  Rebuilds the acceleration structure. */
+ * n_triangles = 0 removes the mesh.  Rebuilds the acceleration structure.
+ * Coordinate range: the triangle rule compares products of four coordinate differences
+ * (det^2 against 2^-40 (e1.e1)(p.p) and (d.d)(n.n)), which leave the float range for edges longer
+ * than ~4e9 or shorter than ~1e-10 world units; such triangles are never hit.  Keep meshes within
+ * 1e-9 .. 1e9 units.
+ * Device memory: 48 bytes per triangle, plus as much again while a replaced mesh of the SAME
+ * triangle count is kept for the next upload (a mesh re-uploaded every frame then allocates
+ * nothing); a replaced mesh of another size, or of a mesh that is removed, is freed at once. */
 int rt_set_mesh(rt_ctx *ctx, const float *vertices, uint32_t n_vertices, const uint32_t *indices,
                 uint32_t n_triangles, const rt_material *material);
 
@@ -221,7 +232,13 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out);
  * RT_STATIC_MAX_TILES tiles of 16x16 pixels (a 7680x4320 image has 129,600).  Results equal
  * rt_render's on a context created with RT_FLAG_FORCE_BRUTE, bit for bit.  Every call on a
  * GPU uses that GPU's one array: calls whose launches overlap on one GPU (different streams or
- * host threads) race; calls on one stream are ordered and safe. */
+ * host threads) race; calls on one stream are ordered and safe.
+ * Under stream capture: the FIRST call on each device looks the array's address up
+ * (hipGetSymbolAddress, which loads the code object) and must therefore happen outside capture --
+ * one ordinary call per device warms it up; later calls only enqueue kernels and one memset on
+ * `stream` and can be captured into a graph and replayed (ubo272 is read at capture time; the
+ * device pointers are baked into the graph).  Every call makes `device` the calling thread's
+ * current device (hipSetDevice) and leaves it so.  `reserved` must be 0. */
 #define RT_STATIC_MAX_SPHERES 1024u
 #define RT_STATIC_MAX_TILES 139264u
 typedef struct rt_static_job {

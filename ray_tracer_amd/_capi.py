@@ -105,7 +105,8 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("last_render_ms", C.c_float),
                 ("total_render_ms", C.c_float), ("last_launches", C.c_uint32),
                 ("bvh_nodes", C.c_uint32), ("last_build_ms", C.c_float), ("bvh_height", C.c_uint32),
-                ("bvh_nodes_visited", C.c_uint64), ("bvh_spheres_tested", C.c_uint64)]
+                ("bvh_nodes_visited", C.c_uint64), ("bvh_spheres_tested", C.c_uint64),
+                ("bvh_fallback", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 lib.rt_last_error.restype = C.c_char_p
@@ -389,13 +390,13 @@ _optional("rt_render_static", [C.POINTER(_StaticJob)])
 def render_static(width: int, height: int, ubo: np.ndarray, d_spheres64: int, n_spheres: int,
                   d_accum: int, d_rgba8: int, d_ids: int, d_rays: int = 0, first_frame: int = 0,
                   n_frames: int = 1, stride: int = 1, flags: int = 0, device: int = 0,
-                  stream: int = 0) -> None:
+                  stream: int = 0, reserved: int = 0) -> None:
     """rt_render_static: the entry point that allocates nothing.  The d_* arguments are device
     addresses (for example torch tensors' data_ptr()); ubo is the 272-byte block on the host."""
     ubo = np.ascontiguousarray(ubo, dtype=np.float32)
     assert ubo.nbytes == 272
     job = _StaticJob(C.sizeof(_StaticJob), device, stream or None, width, height, flags, n_spheres,
-                     ubo.ctypes.data, d_spheres64 or None, first_frame, n_frames, stride, 0,
+                     ubo.ctypes.data, d_spheres64 or None, first_frame, n_frames, stride, reserved,
                      d_accum or None, d_rgba8 or None, d_ids or None, d_rays or None)
     _check(lib.rt_render_static(C.byref(job)))
 

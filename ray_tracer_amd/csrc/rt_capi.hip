@@ -87,6 +87,8 @@ struct rt_ctx {
   uint32_t n_tris = 0;
   uint32_t n_tris_alloc = 0;     // triangles d_tri was allocated for
   float4 *d_tri_spare = nullptr; // the previous mesh's array, reused by an upload of the same size
+  bool bvh_fallback = false;     // an LBVH was built but is too tall to traverse: brute force instead
+  uint32_t bvh_height_limit = (uint32_t)rt::kBvhStackEntries;  // RT_BVH_MAX_HEIGHT lowers it (test hook for the fallback)
   uint32_t tri_spare_n = 0;
   float mesh_lo[3] = {0, 0, 0}, mesh_hi[3] = {0, 0, 0};  // bounds of the mesh vertices
   float mesh_material[12] = {0};
@@ -196,6 +198,7 @@ rt::Scene scene_view(const rt_ctx *c) {
 int rebuild_accel(rt_ctx *c) {
   const uint32_t n_prims = c->n_spheres + c->n_tris;
   c->use_bvh = false;
+  c->bvh_fallback = false;
   const bool want = (c->flags & RT_FLAG_FORCE_BVH) != 0 ||
                     (!(c->flags & RT_FLAG_FORCE_BRUTE) && n_prims > 16u);
   if (!want || n_prims == 0) return RT_OK;
@@ -206,11 +209,10 @@ int rebuild_accel(rt_ctx *c) {
                         c->mesh_hi, c->n_tris, cam, c->stream, &err);
   if (rc != RT_OK) return fail(rc, "LBVH build: %s", err.c_str());
   std::memcpy(c->bvh_cam, cam, sizeof cam);
-  if (c->bvh.height > (uint32_t)rt::kBvhStackEntries) {
+  if (c->bvh.height > c->bvh_height_limit) {
     // taller than any launch can give a stack for: trace by brute force (correct, slow) and
-    // say so; the upload itself succeeds
-    fail(RT_OK, "LBVH height %u exceeds the traversal stack (%d): scene is traced by brute force",
-         c->bvh.height, rt::kBvhStackEntries);
+    // say so in rt_stats.bvh_fallback; the upload itself succeeds and rt_last_error is left alone
+    c->bvh_fallback = true;
     return RT_OK;
   }
   c->use_bvh = true;
@@ -287,6 +289,8 @@ static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
   if ((e = hipMemsetAsync(c->d_tile_cost, 0, c->n_tiles * sizeof(uint32_t), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(tile cost)");
   if (const char *env = std::getenv("RT_TILE_ORDER")) c->use_tile_order = env[0] != '0';
+  if (const char *env = std::getenv("RT_BVH_MAX_HEIGHT"))
+    c->bvh_height_limit = std::min<uint32_t>((uint32_t)std::strtoul(env, nullptr, 10), (uint32_t)rt::kBvhStackEntries);
   if (const char *env = std::getenv("RT_TILE_PROBE")) c->use_probe = env[0] != '0';
   int rc = rt_clear(c);
   if (rc != RT_OK) {
@@ -530,10 +534,18 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
   c->have_scene = false;  // restored once everything below has succeeded (see rt_set_spheres)
   c->use_bvh = false;
   c->n_tris = 0;
-  // the outgoing triangle array becomes the spare for the next upload of the same size
+  // the outgoing triangle array becomes the spare for the next upload -- when it has the size of the
+  // incoming one, the sign of a mesh re-uploaded every frame; anything else is freed now instead of
+  // sitting dead (48 bytes per triangle) until the context goes
   if (c->d_tri_spare) RT_HIP(hipFree(c->d_tri_spare));
-  c->d_tri_spare = c->d_tri;
-  c->tri_spare_n = c->n_tris_alloc;
+  c->d_tri_spare = nullptr;
+  c->tri_spare_n = 0;
+  if (c->d_tri && c->n_tris_alloc == n_triangles && n_triangles) {
+    c->d_tri_spare = c->d_tri;
+    c->tri_spare_n = c->n_tris_alloc;
+  } else if (c->d_tri) {
+    RT_HIP(hipFree(c->d_tri));
+  }
   c->d_tri = new_tri;
   c->n_tris_alloc = n_triangles;
   if (material) std::memcpy(c->mesh_material, material, sizeof c->mesh_material);
@@ -804,6 +816,8 @@ static int rt_get_stats_impl(rt_ctx *c, rt_stats *out) {
   out->bvh_nodes = c->use_bvh ? c->bvh.n_nodes : 0u;
   out->last_build_ms = c->bvh.build_ms();
   out->bvh_height = c->use_bvh ? c->bvh.height : 0u;
+  out->bvh_fallback = c->bvh_fallback ? 1u : 0u;
+  out->reserved = 0u;
   out->bvh_nodes_visited = counters[1];
   out->bvh_spheres_tested = counters[2];
   return RT_OK;
@@ -888,6 +902,7 @@ int rt_render_static(const rt_static_job *job) {
   if (job->flags & ~(uint32_t)(RT_FLAG_STRICT_MATH | RT_FLAG_ACCUM_LINEAR))
     return fail(RT_ERR_INVALID, "rt_render_static: flags 0x%x (strict math and linear accumulation only)", job->flags);
   if (job->frame_stride == 0) return fail(RT_ERR_INVALID, "rt_render_static: frame_stride must be >= 1");
+  if (job->reserved != 0) return fail(RT_ERR_INVALID, "rt_render_static: reserved must be 0");
   if (job->device < 0 || job->device >= kMaxDevices)
     return fail(RT_ERR_INVALID, "rt_render_static: device %d", job->device);
   if (job->n_frames == 0) return RT_OK;

@@ -37,7 +37,7 @@ def test_contract_layout_compiles_as_c(tmp_path):
 
 def test_struct_sizes_in_the_binding():
     assert C.sizeof(rt.Camera) == 36
-    assert C.sizeof(rt.Stats) == 56
+    assert C.sizeof(rt.Stats) == 64
     assert rt.default_ubo().nbytes == 272 and rt.default_scene().nbytes == 192
 
 

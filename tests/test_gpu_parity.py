@@ -1205,6 +1205,53 @@ def test_lbvh_tall_tree_from_clustered_primitives(oracle):
         assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
 
 
+def test_lbvh_too_tall_falls_back_to_brute_force_and_says_so(oracle, monkeypatch):
+    """A tree taller than the traversal stack (64 levels; RT_BVH_MAX_HEIGHT lowers the limit for this
+    test) is not an error: the scene is traced by brute force, rt_stats.bvh_fallback says so,
+    rt_last_error stays untouched, and the image is the brute-force image bit for bit."""
+    w, h = 96, 64
+    ubo = rt.make_ubo(w, h, 2, 5)
+    sph = rt.grid_spheres_scene(300)
+    want = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BRUTE)
+    tall = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+    assert tall["stats"].bvh_fallback == 0 and tall["stats"].bvh_nodes == 299 and tall["stats"].bvh_height > 4
+    monkeypatch.setenv("RT_BVH_MAX_HEIGHT", "4")
+    for mode in (rt.MODE_MEGAKERNEL, rt.MODE_WAVEFRONT):
+        got = gpu_render(ubo, sph, w, h, mode, rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH)
+        assert got["stats"].bvh_fallback == 1 and got["stats"].bvh_nodes == 0 and got["stats"].bvh_height == 0
+        assert np.array_equal(_bits(got["accum"]), _bits(want["accum"])) and got["rays"] == want["rays"]
+        assert np.array_equal(got["ids"], want["ids"])
+    assert want["stats"].bvh_fallback == 0
+
+
+def test_replaced_mesh_arrays_do_not_pile_up():
+    """rt_set_mesh keeps the outgoing triangle array only for a re-upload of the SAME triangle count; a mesh
+    of another size, or a removed mesh, leaves no dead copy behind (48 bytes per triangle)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 400_000                                   # 19.2 MB of triangles
+    rng = np.random.default_rng(5)
+    v = (rng.uniform(-5, 5, (1000, 3)) + np.array([0, 0, -20.0])).astype(np.float32)
+    t = rng.integers(0, 1000, (n, 3)).astype(np.uint32)
+    mat = rt.matte(0.5, 0.5, 0.5)
+    with rt.Renderer(64, 48, flags=rt.FLAG_FORCE_BRUTE) as r:
+        r.set_params(rt.make_ubo(64, 48, 1, 1))
+        r.set_spheres(rt.default_scene())
+        torch.cuda.synchronize(dev)
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        r.set_mesh(v, t, mat)
+        r.set_mesh(v, t, mat)                     # same size: the first array is kept as the spare
+        held_same = free0 - torch.cuda.mem_get_info(dev)[0]
+        r.set_mesh(v, t[: n // 2], mat)           # another size: the spare and the outgoing array are freed
+        held_half = free0 - torch.cuda.mem_get_info(dev)[0]
+        r.set_mesh(v, t[:0], mat)                 # mesh removed
+        held_none = free0 - torch.cuda.mem_get_info(dev)[0]
+    tri = n * 48
+    assert held_same >= 2 * tri * 0.9
+    assert held_half <= 0.5 * tri * 1.2 + (8 << 20)
+    assert held_none <= (8 << 20)
+
+
 def test_converged_image_fast_math_against_the_oracle(oracle):
     """Converged-image tolerance (BASELINE north_star): the benchmarked fast-math launch against
     the CPU ORACLE's image on the same seeds at 1,024 samples per pixel (16 progressive frames of

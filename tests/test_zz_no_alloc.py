@@ -109,3 +109,43 @@ def test_static_entry_point_rejects_sizes_beyond_its_scratch():
         rt.render_static(64, 64, ubo, p, 3, 0, p, p)
     with pytest.raises(rt.RtError):
         rt.render_static(64, 64, ubo, p, 3, p, p, p, stride=0)
+    with pytest.raises(rt.RtError, match="reserved"):
+        rt.render_static(64, 64, ubo, p, 3, p, p, p, reserved=7)
+
+
+def test_static_entry_point_captured_into_a_graph_and_replayed():
+    """What the entry point is for: after one ordinary call on the device (which looks the scratch
+    array's address up), a call under stream capture records its kernels and its one memset into a
+    HIP graph; every replay renders the frames again into the same buffers."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h = 120, 72
+    ubo = rt.make_ubo(w, h, 18, 7, sun_intensity=1.0)
+    sph = rt.grid_spheres_scene(24)
+    sph[1:, 2] += 55.0
+    want = _reference(ubo, sph, w, h, 0, 3, 2, 1)
+    _static(rt.make_ubo(16, 16, 1, 1), rt.default_scene(), 16, 16, 0, 0, 1, 1)     # warm-up, outside capture
+    d_sph = torch.from_numpy(np.ascontiguousarray(sph, dtype=np.float32)).to(dev)
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    rgba8 = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+    ids = torch.full((h, w), -1, dtype=torch.int32, device=dev)
+    rays = torch.zeros(1, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rt.render_static(w, h, ubo, d_sph.data_ptr(), sph.shape[0], accum.data_ptr(), rgba8.data_ptr(),
+                         ids.data_ptr(), rays.data_ptr(), 3, 2, 1, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    assert int(rays.item()) == 0 and not accum.any().item()      # capture records, it does not run
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    got = dict(accum=accum.cpu().numpy(), rgba8=rgba8.cpu().numpy(), ids=ids.cpu().numpy(), rays=int(rays.item()))
+    _same(got, want)
+    graph.replay()                                                # the same two frames once more
+    torch.cuda.synchronize(dev)
+    assert int(rays.item()) == 2 * want["rays"]
+    twice = accum.cpu().numpy()
+    assert (twice[..., 3] == 4).all()
+    # ((a + b) + a) + b against 2 (a + b): the same four addends, another order
+    assert np.max(np.abs(twice - 2.0 * want["accum"])) <= 4 * 2.0 ** -23 * np.max(want["accum"])
