@@ -21,7 +21,8 @@ struct Lbvh {
   uint32_t n_nodes = 0;
   uint32_t capacity = 0;           // spheres the arrays above can hold
   uint32_t height = 0;             // longest root-to-leaf path in edges = traversal stack bound
-  uint32_t refit_passes = 0;
+  uint32_t refit_listed = 0;       // last build: nodes finished by the second refit launch, and its rounds
+  uint32_t refit_rounds = 0;
   float last_build_ms = 0.f;     // use build_ms()
   bool timing_pending = false;
   float build_ms();              // device time of the last build (waits for it if it is still running)

@@ -6,8 +6,8 @@
 //   3. stable LSD radix sort of (code, index), 4 passes of 8 bits     k_rs_hist / k_rs_scan / k_rs_scatter
 //   4. Karras (2012) radix-tree hierarchy over the sorted codes,      k_hierarchy
 //      ties broken by sorted position
-//   5. bottom-up bounds, level-synchronous across launches            k_refit
-//   6. nodes with both child boxes inline (one 64-byte fetch per      (written by k_refit)
+//   5. bottom-up bounds in two or three launches                      k_refit_local / k_refit_upper
+//   6. nodes with both child boxes inline (one 64-byte fetch per      (written by the refit kernels)
 //      traversal step), geometry permuted into leaf order             k_permute
 //
 // Why the leaf boxes are inflated.  The closest-hit search must return exactly what the
@@ -24,11 +24,21 @@
 // on their root path and stretch the Morton grid.  Their leaves become null leaves with an
 // empty box and the traversal tests them first from a short list.
 //
-// Refit without intra-launch hand-offs.  A node may be finished in pass p only from
-// children that were finished in an EARLIER launch (their stamp is non-zero and < p), so
-// every value it reads crossed a kernel boundary; a thread that finishes a node climbs
-// to the parent right away when the sibling is such an earlier node.  No fences, no
-// dependence on dispatch order or on which XCD a block runs.
+// Refit without hand-offs between workgroups.  A node of the radix tree covers a contiguous run
+// of sorted positions, and its index is one end of that run.  k_refit_local gives every block a
+// tile of kRefitTile consecutive positions and lets it finish, in rounds separated by workgroup
+// barriers, every node whose run lies inside the tile (its children's runs then do too, so all it
+// reads was written by its own block, and a barrier orders that); the nodes that straddle a tile
+// boundary -- about a dozen per boundary -- go onto a list.  k_refit_upper finishes the listed
+// nodes the same way, first (when there are several) inside tiles of 2^17 positions, one block
+// per tile, then, in ONE block, whatever is left: their children are either listed too and lie in
+// the same tile (same block) or were finished by an earlier launch.  A node is finished in round r
+// only from children finished in a round before r, so it never reads a box that is being written;
+// the rounds run on LDS and registers, global memory is read before them and written after them.
+// No fences, no flags polled across CUs, no dependence on dispatch order or on which XCD a block
+// runs, and ONE look at the device from the host, when the tree is complete (it was 16 launches
+// of a kernel over all nodes and a read-back per round of them: 224 of the 460 microseconds of a
+// million-triangle build; now 140 in three launches, the build 380).
 #include "rt_lbvh.h"
 
 #include <algorithm>
@@ -376,13 +386,10 @@ __device__ __forceinline__ int delta(const uint32_t *__restrict__ codes, int n, 
 // child encoding: >= 0 internal node index, < 0 leaf at sorted position ~child
 __global__ __launch_bounds__(kThreads) void k_hierarchy(const uint32_t *__restrict__ codes, int n,
                                                         int *__restrict__ left, int *__restrict__ right,
-                                                        int *__restrict__ parent,
-                                                        int *__restrict__ leaf_parent,
                                                         int *__restrict__ range_first,
                                                         int *__restrict__ range_count) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n - 1) return;
-  if (i == 0) parent[0] = -1;
   const int d = (delta(codes, n, i, i + 1) - delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
   const int dmin = delta(codes, n, i, i - d);
   int lmax = 2;
@@ -406,15 +413,13 @@ __global__ __launch_bounds__(kThreads) void k_hierarchy(const uint32_t *__restri
   right[i] = rc;
   range_first[i] = lo;  // the node covers sorted positions lo .. hi
   range_count[i] = hi - lo + 1;
-  if (lc < 0) leaf_parent[gamma] = i; else parent[lc] = i;
-  if (rc < 0) leaf_parent[gamma + 1] = i; else parent[rc] = i;
 }
 
 struct RefitView {
-  const int *left, *right, *parent;
+  const int *left, *right;
   const int *range_first, *range_count;  // sorted positions under each internal node
   const uint32_t *sorted_prim;        // sorted position -> original index
-  const float4 *leaf_lo, *leaf_hi;    // by original index
+  const float4 *leaf_lo, *leaf_hi;    // by sorted position (k_permute)
   uint32_t *stamp;                    // pass in which a node was finished, 0 = not yet
   float4 *box_lo, *box_hi;            // bounds of finished nodes; .w of box_lo = subtree height
   BvhNode *nodes;
@@ -439,9 +444,8 @@ __device__ __forceinline__ void child_box(const RefitView &v, int &c, float4 &lo
                                           float &height) {
   if (c < 0) {
     const uint32_t pos = (uint32_t)~c;
-    const uint32_t prim = v.sorted_prim[pos];
-    lo = v.leaf_lo[prim];
-    hi = v.leaf_hi[prim];
+    lo = v.leaf_lo[pos];
+    hi = v.leaf_hi[pos];
     height = 0.f;
     c = lo.w != 0.f ? kNullLeaf : make_leaf_ref(pos, 1u);
   } else {
@@ -469,46 +473,409 @@ __device__ __forceinline__ void finish_node(const RefitView &v, int i, int c0, i
   v.stamp[i] = pass;
 }
 
-__global__ __launch_bounds__(kThreads) void k_refit(RefitView v, uint32_t pass) {
-  int i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= v.n_internal || v.stamp[i] != 0u) return;
+constexpr int kRefitTile = 2048;                     // sorted positions (and node indices) per block of k_refit_local
+constexpr int kRefitThreads = 1024;
+constexpr int kRefitE = kRefitTile / kRefitThreads;  // nodes per thread
+constexpr int kTopCap = 3072;                        // listed nodes k_refit_top keeps in LDS (more: its slow path)
+constexpr int kTopE = kTopCap / 1024;
+constexpr uint32_t kTopPassBase = 0x01000000u;       // slow path: its rounds are numbered from here (above any local round)
+constexpr uint32_t kListedBit = 0x80000000u;         // stamp of a listed node until it is finished: this bit | its slot
+
+// A child as its parent sees it while the parent waits: `wait` >= 0 is the LDS slot of a child that the
+// same kernel has yet to finish (its box is read from LDS then), -1 a child whose box is already here.
+struct PendingChild {
+  int ref;        // what the parent's record will hold: node index, leaf reference or kNullLeaf
+  int wait;
+  bool folded;    // an internal child of at most kLeafMaxPrims primitives: referenced as a leaf, height 0
+  float lo[3], hi[3], height;
+};
+
+__device__ __forceinline__ void write_node(const RefitView &v, int i, const PendingChild &a, const PendingChild &b,
+                                           float box[7]) {
+  float4 *out = (float4 *)(v.nodes + i);
+  out[0] = make_float4(a.lo[0], a.lo[1], a.lo[2], __int_as_float(a.ref));
+  out[1] = make_float4(a.hi[0], a.hi[1], a.hi[2], __int_as_float(0));
+  out[2] = make_float4(b.lo[0], b.lo[1], b.lo[2], __int_as_float(b.ref));
+  out[3] = make_float4(b.hi[0], b.hi[1], b.hi[2], __int_as_float(0));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    box[k] = fminf(a.lo[k], b.lo[k]);
+    box[3 + k] = fmaxf(a.hi[k], b.hi[k]);
+  }
+  box[6] = fmaxf(a.height, b.height) + 1.f;
+}
+
+// meta: [0] number of listed nodes, [1] height of the tree, [2] 1 once the root is finished, [3] rounds of k_refit_top
+__global__ __launch_bounds__(kRefitThreads) void k_refit_local(RefitView v, uint32_t *__restrict__ top_list,
+                                                               uint32_t *meta) {
+  __shared__ float leaf_b[6][kRefitTile];           // boxes of the tile's leaves
+  __shared__ unsigned char leaf_null[kRefitTile];   // leaf of an oversized sphere (kept out of the tree)
+  __shared__ float node_b[7][kRefitTile];           // boxes and heights of the tile's finished nodes
+  __shared__ unsigned short node_round[kRefitTile]; // round in which a node was finished, 0: not yet
+  __shared__ unsigned char has_parent[kRefitTile];  // its parent lies inside the tile too
+  __shared__ uint32_t n_listed, list_base;
+  __shared__ int moved[3];                          // "a node was finished in round r" at [r % 3]
+  const int base = blockIdx.x * kRefitTile;
+  const int n_leaves = v.n_internal + 1;
+  if (threadIdx.x == 0) {
+    n_listed = 0;
+    moved[0] = moved[1] = moved[2] = 0;
+  }
+  for (int p = threadIdx.x; p < kRefitTile; p += kRefitThreads) {
+    node_round[p] = 0;
+    has_parent[p] = 0;
+    if (base + p < n_leaves) {
+      const float4 lo = v.leaf_lo[base + p], hi = v.leaf_hi[base + p];
+      leaf_b[0][p] = lo.x; leaf_b[1][p] = lo.y; leaf_b[2][p] = lo.z;
+      leaf_b[3][p] = hi.x; leaf_b[4][p] = hi.y; leaf_b[5][p] = hi.z;
+      leaf_null[p] = lo.w != 0.f;
+    }
+  }
+  // this thread's nodes: inside the tile (todo) or across its boundary (outside)
+  uint32_t todo = 0, outside = 0;
+  int child[kRefitE][2], ref[kRefitE][2];
+#pragma unroll
+  for (int k = 0; k < kRefitE; ++k) {
+    const int i = base + k * kRefitThreads + (int)threadIdx.x;
+    child[k][0] = child[k][1] = ref[k][0] = ref[k][1] = 0;
+    if (i >= v.n_internal) continue;
+    const int first = v.range_first[i], count = v.range_count[i];
+    if (!(first >= base && first + count <= base + kRefitTile)) {
+      outside |= 1u << k;
+      continue;
+    }
+    todo |= 1u << k;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int c = side ? v.right[i] : v.left[i];
+      child[k][side] = c;
+      ref[k][side] = c;
+      if (c >= 0) {   // a small subtree is referenced as one leaf
+        const int cc = v.range_count[c];
+        if (cc <= kLeafMaxPrims) ref[k][side] = make_leaf_ref((uint32_t)v.range_first[c], (uint32_t)cc);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t inside = todo;
+#pragma unroll
+  for (int k = 0; k < kRefitE; ++k)
+    if (inside & (1u << k)) {
+      if (child[k][0] >= 0) has_parent[child[k][0] - base] = 1;
+      if (child[k][1] >= 0) has_parent[child[k][1] - base] = 1;
+    }
+  // children of node k of this thread, as its record will hold them, from the tile's LDS
+  auto gather = [&](int k, PendingChild pc[2]) {
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int c = child[k][side];
+      if (c < 0) {
+        const int p = ~c - base;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          pc[side].lo[q] = leaf_b[q][p];
+          pc[side].hi[q] = leaf_b[3 + q][p];
+        }
+        pc[side].height = 0.f;
+        pc[side].ref = leaf_null[p] ? kNullLeaf : make_leaf_ref((uint32_t)~c, 1u);
+      } else {
+        const int p = c - base;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          pc[side].lo[q] = node_b[q][p];
+          pc[side].hi[q] = node_b[3 + q][p];
+        }
+        pc[side].ref = ref[k][side];
+        pc[side].height = ref[k][side] < 0 ? 0.f : node_b[6][p];
+      }
+    }
+  };
+  // The rounds touch LDS only (a barrier waits for the wave's outstanding global stores too, and with a
+  // store per finished node every one of ~25 rounds waited a memory round trip); the records go out
+  // to global memory after the last round.
+  for (uint32_t pass = 1;; ++pass) {
+    bool progress = false;
+#pragma unroll
+    for (int k = 0; k < kRefitE; ++k) {
+      if (!(todo & (1u << k))) continue;
+      bool ready = true;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int c = child[k][side];
+        if (c >= 0) {
+          const uint32_t r = node_round[c - base];
+          ready = ready && r != 0u && r < pass;
+        }
+      }
+      if (!ready) continue;
+      PendingChild pc[2];
+      gather(k, pc);
+      const int p = k * kRefitThreads + (int)threadIdx.x;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        node_b[q][p] = fminf(pc[0].lo[q], pc[1].lo[q]);
+        node_b[3 + q][p] = fmaxf(pc[0].hi[q], pc[1].hi[q]);
+      }
+      node_b[6][p] = fmaxf(pc[0].height, pc[1].height) + 1.f;
+      node_round[p] = (unsigned short)pass;
+      todo &= ~(1u << k);
+      progress = true;
+    }
+    // One barrier per round: it orders this round's LDS stores before the next round's loads, and
+    // behind it everyone reads whether anyone moved.  (Three flags in rotation: the one for the next
+    // round is cleared now, while nobody can still be reading it.)
+    if (progress) moved[pass % 3u] = 1;
+    if (threadIdx.x == 0) moved[(pass + 1u) % 3u] = 0;
+    __syncthreads();
+    if (!moved[pass % 3u]) break;
+  }
+  // every node inside the tile is finished now (its whole subtree is inside the tile): the records, and
+  // for the nodes whose parent is not in the tile the box and a stamp, which a later launch reads
+#pragma unroll
+  for (int k = 0; k < kRefitE; ++k) {
+    if (!(inside & (1u << k))) continue;
+    PendingChild pc[2];
+    gather(k, pc);
+    const int i = base + k * kRefitThreads + (int)threadIdx.x;
+    float box[7];
+    write_node(v, i, pc[0], pc[1], box);
+    if (!has_parent[i - base]) {   // the root of a subtree of this tile: a later launch reads its box
+      v.box_lo[i] = make_float4(box[0], box[1], box[2], box[6]);
+      v.box_hi[i] = make_float4(box[3], box[4], box[5], 0.f);
+      v.stamp[i] = node_round[i - base];
+    }
+  }
+  // the nodes across the tile's boundary go onto the list
+  uint32_t slot = 0;
+  const uint32_t mine = (uint32_t)__builtin_popcount(outside);
+  if (mine) slot = atomicAdd(&n_listed, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && n_listed) list_base = atomicAdd(meta, n_listed);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kRefitE; ++k)
+    if (outside & (1u << k)) {
+      const uint32_t i = (uint32_t)(base + k * kRefitThreads + (int)threadIdx.x);
+      top_list[list_base + slot] = i;
+      v.stamp[i] = kListedBit | (list_base + slot);
+      ++slot;
+    }
+}
+
+// slow path of k_refit_top: one attempt at node i in round `pass` on global memory
+__device__ __forceinline__ bool try_finish(const RefitView &v, int i, uint32_t pass) {
   int c0 = v.left[i], c1 = v.right[i];
-  if (!child_ready(v, c0, pass) || !child_ready(v, c1, pass)) return;
+  if (!child_ready(v, c0, pass) || !child_ready(v, c1, pass)) return false;
   float4 l0, h0, l1, h1, lo, hi;
   float ht0, ht1, height;
   child_box(v, c0, l0, h0, ht0);
   child_box(v, c1, l1, h1, ht1);
   finish_node(v, i, c0, c1, l0, h0, ht0, l1, h1, ht1, pass, lo, hi, height);
-  // climb while the sibling was finished by an earlier launch
-  for (;;) {
-    const int p = v.parent[i];
-    if (p < 0) break;
-    int pc0 = v.left[p], pc1 = v.right[p];
-    const bool i_is_left = (pc0 == i);
-    int sib = i_is_left ? pc1 : pc0;
-    if (!child_ready(v, sib, pass)) break;
-    float4 sl, sh;
-    float sht;
-    child_box(v, sib, sl, sh, sht);
-    float4 nlo, nhi;
-    float nh;
-    int self = i;
-    fold_small_subtree(v, self, height);
-    if (i_is_left) finish_node(v, p, self, sib, lo, hi, height, sl, sh, sht, pass, nlo, nhi, nh);
-    else finish_node(v, p, sib, self, sl, sh, sht, lo, hi, height, pass, nlo, nhi, nh);
-    lo = nlo; hi = nhi; height = nh;
-    i = p;
+  return true;
+}
+
+// The listed nodes, level by level.  A launch with tile_shift = t finishes every listed node whose run of
+// sorted positions lies inside one tile of 2^t positions (block b takes tile b); the last launch, one
+// block with t = 32, takes whatever is left.  A block picks its nodes off the list, gives them LDS slots
+// (the stamp of a picked node becomes kListedBit | its slot, which is how a parent finds a child that
+// the same block finishes), fetches the boxes of children that an earlier launch finished, and then
+// runs the rounds on registers and LDS alone.  A block that finds more nodes than it has slots leaves
+// them to the last launch, which falls back to rounds on global memory when it, too, has too many.
+__global__ __launch_bounds__(1024) void k_refit_upper(RefitView v, const uint32_t *__restrict__ top_list,
+                                                      uint32_t *meta, uint32_t tile_shift, uint32_t last) {
+  __shared__ float nb[7][kTopCap];
+  __shared__ unsigned short rnd[kTopCap];
+  __shared__ int slot_node[kTopCap];
+  __shared__ uint32_t wave_base[16], n_picked;
+  __shared__ int moved[3];
+  const uint32_t n_listed = meta[0];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) moved[0] = moved[1] = moved[2] = 0;
+  // ---- pick: unfinished listed nodes whose run lies in this block's tile, counted, then numbered
+  auto mine = [&](uint32_t j) -> int {
+    if (j >= n_listed) return -1;
+    const int i = (int)top_list[j];
+    if (!(v.stamp[i] & kListedBit)) return -1;   // finished by an earlier launch
+    if (tile_shift < 32u) {
+      const uint32_t first = (uint32_t)v.range_first[i], end = first + (uint32_t)v.range_count[i] - 1u;
+      if ((first >> tile_shift) != blockIdx.x || (end >> tile_shift) != blockIdx.x) return -1;
+    }
+    return i;
+  };
+  uint32_t count = 0;
+  for (uint32_t j0 = 0; j0 < n_listed; j0 += 1024u) count += mine(j0 + threadIdx.x) >= 0 ? 1u : 0u;
+  // exclusive prefix over the block's threads: within the wave by shuffles, across waves through LDS
+  uint32_t inc = count;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc += up;
+  }
+  if (lane == 63u) wave_base[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t c = wave_base[w];
+      wave_base[w] = run;
+      run += c;
+    }
+    n_picked = run;
+  }
+  __syncthreads();
+  const uint32_t picked = n_picked;
+  uint32_t rounds = 0;
+  bool done = false;
+  float height = 0.f;
+  if (picked > (uint32_t)kTopCap) {
+    if (!last) return;   // too many for this block's LDS: the last launch takes them
+    // the last launch, with more nodes than LDS holds (tens of millions of primitives): rounds on global memory
+    for (uint32_t pass = kTopPassBase;; ++pass) {
+      bool progress = false;
+      for (uint32_t j = threadIdx.x; j < n_listed; j += 1024u) {
+        const int i = (int)top_list[j];
+        if (!(v.stamp[i] & kListedBit)) continue;
+        if (try_finish(v, i, pass)) progress = true;
+      }
+      ++rounds;
+      if (!__syncthreads_or(progress)) break;
+    }
+  } else if (picked) {
+    uint32_t slot = wave_base[wave] + inc - count;
+    for (uint32_t j0 = 0; j0 < n_listed; j0 += 1024u) {
+      const int i = mine(j0 + threadIdx.x);
+      if (i < 0) continue;
+      slot_node[slot] = i;
+      rnd[slot] = 0;
+      ++slot;
+    }
+    __syncthreads();
+    // (stamps are rewritten only now, after every thread has done its second look at them)
+    for (uint32_t q = threadIdx.x; q < picked; q += 1024u) v.stamp[slot_node[q]] = kListedBit | q;
+    __syncthreads();
+    int node[kTopE];
+    PendingChild pc[kTopE][2];
+    uint32_t todo = 0;
+#pragma unroll
+    for (int k = 0; k < kTopE; ++k) {
+      const uint32_t q = (uint32_t)k * 1024u + threadIdx.x;
+      node[k] = -1;
+      if (q >= picked) continue;
+      const int i = slot_node[q];
+      node[k] = i;
+      todo |= 1u << k;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        PendingChild &c = pc[k][side];
+        const int cc = side ? v.right[i] : v.left[i];
+        c.wait = -1;
+        c.folded = false;
+        float4 lo, hi;
+        if (cc < 0) {
+          lo = v.leaf_lo[~cc];
+          hi = v.leaf_hi[~cc];
+          c.ref = lo.w != 0.f ? kNullLeaf : make_leaf_ref((uint32_t)~cc, 1u);
+          c.height = 0.f;
+        } else {
+          const uint32_t st = v.stamp[cc];
+          const int n_under = v.range_count[cc];
+          c.folded = n_under <= kLeafMaxPrims;
+          c.ref = c.folded ? make_leaf_ref((uint32_t)v.range_first[cc], (uint32_t)n_under) : cc;
+          if (st & kListedBit) {   // a child of a picked node that is still listed was picked too
+            c.wait = (int)(st & ~kListedBit);
+            lo = hi = make_float4(0.f, 0.f, 0.f, 0.f);
+            c.height = 0.f;
+          } else {
+            lo = v.box_lo[cc];
+            hi = v.box_hi[cc];
+            c.height = c.folded ? 0.f : lo.w;
+          }
+        }
+        c.lo[0] = lo.x; c.lo[1] = lo.y; c.lo[2] = lo.z;
+        c.hi[0] = hi.x; c.hi[1] = hi.y; c.hi[2] = hi.z;
+      }
+    }
+    __syncthreads();
+    for (uint32_t pass = 1;; ++pass) {
+      bool progress = false;
+#pragma unroll
+      for (int k = 0; k < kTopE; ++k) {
+        if (!(todo & (1u << k))) continue;
+        bool ready = true;
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+          if (pc[k][side].wait >= 0) {
+            const uint32_t r = rnd[pc[k][side].wait];
+            ready = ready && r != 0u && r < pass;
+          }
+        if (!ready) continue;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          PendingChild &c = pc[k][side];
+          if (c.wait >= 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              c.lo[q] = nb[q][c.wait];
+              c.hi[q] = nb[3 + q][c.wait];
+            }
+            c.height = c.folded ? 0.f : nb[6][c.wait];
+          }
+        }
+        const uint32_t q = (uint32_t)k * 1024u + threadIdx.x;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          nb[e][q] = fminf(pc[k][0].lo[e], pc[k][1].lo[e]);
+          nb[3 + e][q] = fmaxf(pc[k][0].hi[e], pc[k][1].hi[e]);
+        }
+        nb[6][q] = fmaxf(pc[k][0].height, pc[k][1].height) + 1.f;
+        rnd[q] = (unsigned short)pass;
+        todo &= ~(1u << k);
+        progress = true;
+      }
+      ++rounds;
+      if (progress) moved[pass % 3u] = 1;
+      if (threadIdx.x == 0) moved[(pass + 1u) % 3u] = 0;
+      __syncthreads();
+      if (!moved[pass % 3u]) break;
+    }
+    // (as in k_refit_local, global memory is written after the rounds: the children are in registers by now)
+#pragma unroll
+    for (int k = 0; k < kTopE; ++k) {
+      if (node[k] < 0 || (todo & (1u << k))) continue;
+      float box[7];
+      write_node(v, node[k], pc[k][0], pc[k][1], box);
+      v.box_lo[node[k]] = make_float4(box[0], box[1], box[2], box[6]);
+      v.box_hi[node[k]] = make_float4(box[3], box[4], box[5], 0.f);
+      v.stamp[node[k]] = rnd[(uint32_t)k * 1024u + threadIdx.x];
+    }
+    __syncthreads();
+  }
+  if (last && threadIdx.x == 0) {
+    // (no progress with nodes left cannot happen in a tree; the host would see meta[2] == 0)
+    done = v.n_internal > 0 && v.stamp[0] != 0u && !(v.stamp[0] & kListedBit);
+    if (done) height = v.box_lo[0].w;
+    meta[1] = done ? (uint32_t)height : 0u;
+    meta[2] = done ? 1u : 0u;
+    meta[3] = rounds;
   }
 }
 
+// geometry and leaf boxes into sorted order: the one gather of the build (the refit kernels then read
+// their leaves' boxes coalesced, from blocks that have few waves to hide a gather behind)
 __global__ __launch_bounds__(kThreads) void k_permute(const float4 *__restrict__ geom,
                                                       uint32_t n_spheres,
                                                       const uint32_t *__restrict__ sorted_prim,
-                                                      float4 *__restrict__ sorted_geom, uint32_t n) {
+                                                      float4 *__restrict__ sorted_geom,
+                                                      const float4 *__restrict__ leaf_lo,
+                                                      const float4 *__restrict__ leaf_hi,
+                                                      float4 *__restrict__ sorted_lo,
+                                                      float4 *__restrict__ sorted_hi, uint32_t n) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
   const uint32_t prim = sorted_prim[i];
   sorted_geom[i] = prim < n_spheres ? geom[prim] : make_float4(0.f, 0.f, 0.f, 0.f);
+  sorted_lo[i] = leaf_lo[prim];
+  sorted_hi[i] = leaf_hi[prim];
 }
 
 }  // namespace
@@ -517,9 +884,11 @@ struct Lbvh::Work {
   size_t capacity = 0;
   char *slab = nullptr;
   float4 *cr = nullptr, *leaf_lo = nullptr, *leaf_hi = nullptr, *box_lo = nullptr, *box_hi = nullptr;
+  float4 *sorted_lo = nullptr, *sorted_hi = nullptr;  // the leaf boxes by sorted position
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr};
   uint32_t *hist = nullptr, *scan_sums = nullptr, *stamp = nullptr, *cbounds = nullptr;
-  int *left = nullptr, *right = nullptr, *parent = nullptr, *leaf_parent = nullptr;
+  int *left = nullptr, *right = nullptr;
+  uint32_t *top_list = nullptr;  // nodes that straddle a tile boundary of k_refit_local
   int *range_first = nullptr, *range_count = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // what the device holds of the host-made inputs (uploads of unchanged content are skipped: a
@@ -599,13 +968,15 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     const size_t f4 = align256((size_t)n * sizeof(float4)), u4 = align256((size_t)n * sizeof(uint32_t));
     const size_t hist = align256((size_t)256 * nblk * sizeof(uint32_t));
     const size_t sums = align256(((size_t)256 * nblk / kScanTile + 2) * sizeof(uint32_t));
-    const size_t total = 5 * f4 + 11 * u4 + hist + sums + 256;
+    const size_t total = 7 * f4 + 10 * u4 + hist + sums + 512;
     BVH_HIP(hipMalloc((void **)&work->slab, total));
     char *p = work->slab;
     auto take = [&](size_t bytes) { char *q = p; p += bytes; return q; };
     work->cr = (float4 *)take(f4);
     work->leaf_lo = (float4 *)take(f4);
     work->leaf_hi = (float4 *)take(f4);
+    work->sorted_lo = (float4 *)take(f4);
+    work->sorted_hi = (float4 *)take(f4);
     work->box_lo = (float4 *)take(f4);
     work->box_hi = (float4 *)take(f4);
     work->keys[0] = (uint32_t *)take(u4);
@@ -615,13 +986,12 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     work->stamp = (uint32_t *)take(u4);
     work->left = (int *)take(u4);
     work->right = (int *)take(u4);
-    work->parent = (int *)take(u4);
-    work->leaf_parent = (int *)take(u4);
+    work->top_list = (uint32_t *)take(u4);
     work->range_first = (int *)take(u4);
     work->range_count = (int *)take(u4);
     work->hist = (uint32_t *)take(hist);
     work->scan_sums = (uint32_t *)take(sums);
-    work->cbounds = (uint32_t *)take(256);
+    work->cbounds = (uint32_t *)take(512);  // six bounds words, and the refit's four words of meta in a 256-byte block of their own
     work->capacity = n;
   }
   Work &w = *work;
@@ -732,54 +1102,51 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, w.scan_sums, scan_tiles);
     hipLaunchKernelGGL(k_scan_apply, dim3(scan_tiles), dim3(kThreads), 0, stream, w.hist, n_counters,
                        w.scan_sums);
+    // the last pass writes the sorted order where the traversal reads it
     hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], w.vals[cur],
-                       w.keys[cur ^ 1], w.vals[cur ^ 1], n, shift, w.hist, nblk);
+                       w.keys[cur ^ 1], shift == 24u ? sorted_prim : w.vals[cur ^ 1], n, shift, w.hist, nblk);
     cur ^= 1;
   }
-  // sorted codes in keys[cur], sorted_prim = vals[cur]
-  BVH_HIP(hipMemcpyAsync(sorted_prim, w.vals[cur], (size_t)n * sizeof(uint32_t),
-                         hipMemcpyDeviceToDevice, stream));
+  // sorted codes in keys[cur], sorted order in sorted_prim
   hipLaunchKernelGGL(k_permute, dim3(blocks_n), dim3(kThreads), 0, stream, d_geom, n_spheres,
-                     sorted_prim, sorted_geom, n);
+                     sorted_prim, sorted_geom, w.leaf_lo, w.leaf_hi, w.sorted_lo, w.sorted_hi, n);
   n_nodes = n - 1;
   height = 0;
   if (n >= 2) {
     const uint32_t blocks_i = (n - 1 + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_hierarchy, dim3(blocks_i), dim3(kThreads), 0, stream, w.keys[cur], (int)n,
-                       w.left, w.right, w.parent, w.leaf_parent, w.range_first, w.range_count);
+                       w.left, w.right, w.range_first, w.range_count);
     BVH_HIP(hipMemsetAsync(w.stamp, 0, (size_t)(n - 1) * sizeof(uint32_t), stream));
+    uint32_t *meta = w.cbounds + 64;
+    BVH_HIP(hipMemsetAsync(meta, 0, 256, stream));
     RefitView rv;
-    rv.left = w.left; rv.right = w.right; rv.parent = w.parent;
+    rv.left = w.left; rv.right = w.right;
     rv.range_first = w.range_first; rv.range_count = w.range_count;
     rv.sorted_prim = sorted_prim;
-    rv.leaf_lo = w.leaf_lo; rv.leaf_hi = w.leaf_hi;
+    rv.leaf_lo = w.sorted_lo; rv.leaf_hi = w.sorted_hi;
     rv.stamp = w.stamp; rv.box_lo = w.box_lo; rv.box_hi = w.box_hi;
     rv.nodes = nodes;
     rv.n_internal = (int)(n - 1);
-    // Passes are launched in rounds, each followed by one look at the root (its stamp, and the
-    // height that comes with its box): as many as the previous build needed to begin with, since
-    // a rebuild of the same mesh in another pose needs about as many, then four at a time.
-    uint32_t pass = 1;
-    uint32_t round = refit_passes ? refit_passes : 8u;
-    for (;;) {
-      for (uint32_t k = 0; k < round; ++k, ++pass)
-        hipLaunchKernelGGL(k_refit, dim3(blocks_i), dim3(kThreads), 0, stream, rv, pass);
-      uint32_t root_stamp = 0;
-      float4 root_lo;
-      BVH_HIP(hipMemcpyAsync(&root_stamp, w.stamp, sizeof root_stamp, hipMemcpyDeviceToHost, stream));
-      BVH_HIP(hipMemcpyAsync(&root_lo, w.box_lo, sizeof root_lo, hipMemcpyDeviceToHost, stream));
-      BVH_HIP(hipStreamSynchronize(stream));
-      if (root_stamp != 0u) {
-        refit_passes = root_stamp;  // the pass that finished the root
-        height = (uint32_t)root_lo.w;
-        break;
-      }
-      if (pass > 4u * 65536u) {
-        if (err) *err = "bounds propagation did not reach the root";
-        return -2;
-      }
-      round = 4u;
+    const uint32_t tiles = (n - 1 + kRefitTile - 1) / kRefitTile;
+    hipLaunchKernelGGL(k_refit_local, dim3(tiles), dim3(kRefitThreads), 0, stream, rv, w.top_list, meta);
+    // the nodes that straddle boundaries of those tiles: first the ones inside tiles of 64 x 2048 positions
+    // (when there are several such tiles), then, in one block, the rest
+    constexpr uint32_t kMidShift = 17;
+    const uint32_t mid_tiles = (n + (1u << kMidShift) - 1u) >> kMidShift;
+    if (mid_tiles > 1u)
+      hipLaunchKernelGGL(k_refit_upper, dim3(mid_tiles), dim3(1024), 0, stream, rv, w.top_list, meta, kMidShift, 0u);
+    hipLaunchKernelGGL(k_refit_upper, dim3(1), dim3(1024), 0, stream, rv, w.top_list, meta, 32u, 1u);
+    // ONE look at the device per build: the height sizes the traversal stack of the launches that follow
+    uint32_t h_meta[4] = {0, 0, 0, 0};
+    BVH_HIP(hipMemcpyAsync(h_meta, meta, sizeof h_meta, hipMemcpyDeviceToHost, stream));
+    BVH_HIP(hipStreamSynchronize(stream));
+    if (h_meta[2] != 1u) {
+      if (err) *err = "bounds propagation did not reach the root";
+      return -2;
     }
+    height = h_meta[1];
+    refit_listed = h_meta[0];
+    refit_rounds = h_meta[3];
   }
   BVH_HIP(hipEventRecord(w.ev1, stream));
   timing_pending = true;  // read by build_ms(), so that no build waits for its own end

@@ -300,6 +300,14 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
   }
   const bool batched = FORM == kRegenMixed ? rank >= O.chain_ranks : FORM == kRegenBatched;
   const uint32_t tile = ordered_tile(O, rank);
+#ifdef RT_DEBUG_SKIP_RANKS
+  // measurement build: the heaviest tiles of an ordered launch are not traced at all (they keep their
+  // place in the order), which shows what the launch would take if their chains cost nothing
+  if (O.tile_order && rank < RT_DEBUG_SKIP_RANKS) {
+    if (threadIdx.x == 0 && O.tile_cost) atomicMax(O.tile_cost + tile, 0x40000000u - rank);
+    return;
+  }
+#endif
   uint32_t px, py;
   pixel_of_tile(tile, O.tiles_x, tile_t, px, py);
   uint32_t nrays = 0;
