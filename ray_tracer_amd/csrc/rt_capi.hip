@@ -264,6 +264,7 @@ static int rt_create_impl(const rt_config *cfg, rt_ctx **out_ctx) {
   // switch point can be overridden for experiments
   c->wf.drain_threshold = (uint32_t)(c->n_pixels / 2);
   if (const char *e = std::getenv("RT_WF_DRAIN_THRESHOLD")) c->wf.drain_threshold = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (const char *e = std::getenv("RT_WF_REGROUP")) c->wf.regroup = e[0] != '0';
 
   auto bail = [&](hipError_t e, const char *what) {
     int rc = fail(RT_ERR_DEVICE, "rt_create: %s: %s", what, hipGetErrorString(e));
@@ -720,6 +721,11 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
   }
   if (he == hipSuccess) {
     if (c->mode == RT_MODE_WAVEFRONT && !degenerate) {
+      if (c->wf.regroup && c->use_bvh)
+        for (int k = 0; k < 3; ++k) {
+          c->wf.regroup_lo[k] = c->bvh.scene_lo[k];
+          c->wf.regroup_hi[k] = c->bvh.scene_hi[k];
+        }
       rc = c->wf.render(strict, c->use_bvh, c->P, S, F, O, c->stream, &launches, &err);
     } else if ((c->flags & RT_FLAG_COUNT_TRAVERSAL) && c->use_bvh && !strict && !degenerate) {
       he = rt::launch_megakernel_counting(c->P, S, F, O, c->stream);

@@ -21,6 +21,7 @@ struct Lbvh {
   uint32_t n_nodes = 0;
   uint32_t capacity = 0;           // spheres the arrays above can hold
   uint32_t height = 0;             // longest root-to-leaf path in edges = traversal stack bound
+  float scene_lo[3] = {0.f, 0.f, 0.f}, scene_hi[3] = {0.f, 0.f, 0.f};  // bounds of sphere centres and mesh vertices
   uint32_t refit_listed = 0;       // last build: nodes finished by the second refit launch, and its rounds
   uint32_t refit_rounds = 0;
   float last_build_ms = 0.f;     // use build_ms()
@@ -39,5 +40,10 @@ struct Lbvh {
   int download(std::vector<BvhNode> *out_nodes, std::vector<uint32_t> *out_prims) const;
   void release();
 };
+
+// The build's radix sort for other users (the wavefront pipeline's ray regrouping experiment)
+hipError_t radix_sort_pairs(uint32_t *const keys[2], uint32_t *const vals[2], uint32_t n, int passes,
+                            uint32_t *hist, uint32_t *scan_sums, hipStream_t stream);
+void radix_sort_scratch(uint32_t n, size_t *hist_bytes, size_t *sums_bytes);
 
 }  // namespace rt

@@ -880,6 +880,31 @@ __global__ __launch_bounds__(kThreads) void k_permute(const float4 *__restrict__
 
 }  // namespace
 
+// Stable LSD radix sort of n (key, value) pairs by the low 8 * passes bits of the key, with the build's
+// own kernels: keys[0] / vals[0] hold the input, the result is in keys[r] / vals[r] with r = passes & 1.
+hipError_t radix_sort_pairs(uint32_t *const keys[2], uint32_t *const vals[2], uint32_t n, int passes,
+                            uint32_t *hist, uint32_t *scan_sums, hipStream_t stream) {
+  const uint32_t nblk = (n + kRsTile - 1) / kRsTile;
+  int cur = 0;
+  for (int pass = 0; pass < passes; ++pass) {
+    const uint32_t shift = 8u * (uint32_t)pass;
+    hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(kThreads), 0, stream, keys[cur], n, shift, hist, nblk);
+    const uint32_t n_counters = 256u * nblk, scan_tiles = (n_counters + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(scan_tiles), dim3(kThreads), 0, stream, hist, n_counters, scan_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, scan_sums, scan_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(scan_tiles), dim3(kThreads), 0, stream, hist, n_counters, scan_sums);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(kThreads), 0, stream, keys[cur], vals[cur], keys[cur ^ 1],
+                       vals[cur ^ 1], n, shift, hist, nblk);
+    cur ^= 1;
+  }
+  return hipGetLastError();
+}
+void radix_sort_scratch(uint32_t n, size_t *hist_bytes, size_t *sums_bytes) {
+  const uint32_t nblk = (n + kRsTile - 1) / kRsTile;
+  *hist_bytes = (size_t)256 * nblk * sizeof(uint32_t);
+  *sums_bytes = ((size_t)256 * nblk / kScanTile + 2) * sizeof(uint32_t);
+}
+
 struct Lbvh::Work {
   size_t capacity = 0;
   char *slab = nullptr;
@@ -1023,6 +1048,10 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
         clo[k] = std::min(clo[k], mesh_lo[k]);
         chi[k] = std::max(chi[k], mesh_hi[k]);
       }
+    for (int k = 0; k < 3; ++k) {
+      scene_lo[k] = clo[k];
+      scene_hi[k] = chi[k];
+    }
     double diag2 = 0.0;
     for (int k = 0; k < 3; ++k) diag2 += ((double)chi[k] - clo[k]) * ((double)chi[k] - clo[k]);
     bp.large_radius = n >= 3 ? (float)(0.1 * std::sqrt(diag2)) : 3.0e38f;

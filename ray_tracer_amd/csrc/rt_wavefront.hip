@@ -35,6 +35,7 @@
 // until its pixel is done (the megakernel's loop, resumed from the stored state).
 #include "rt_wavefront.h"
 
+#include "rt_lbvh.h"
 #include "rt_shading.h"
 #include "rt_traverse.h"
 
@@ -51,7 +52,39 @@ struct WfView {
   uint32_t *q;       // one slice of kWfChunk entries per extend block; also the drain queue
   uint2 *slice;      // per extend block: hits at the front, misses at the back of its slice
   uint32_t *counts;  // [4 slots][4]: -, hits, misses, - (totals); [16]: length of the drain queue
+  const uint32_t *order;  // regrouping experiment: the extend stage's k-th entry is pixel order[k]; null: pixel k
 };
+
+struct RegroupGrid {
+  float lo[3], scale[3];  // cell = clamp((origin - lo) * scale, 0, 15) per axis
+};
+// Sort key of every pixel for the regrouping experiment: 12 bits of Morton-interleaved cell of the ray's
+// origin, 3 bits of direction octant; pixels without a live path sort to the end.
+__global__ __launch_bounds__(256) void k_wf_keys(WfView V, uint32_t n_pixels, RegroupGrid G, uint32_t *keys,
+                                                 uint32_t *vals) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_pixels) return;
+  uint32_t key = 0xffffu;
+  if (V.alive[i]) {
+    const float4 p0 = V.P0[i], p1 = V.P1[i];
+    const float o[3] = {p0.x, p0.y, p0.z};
+    uint32_t cell[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float t = (o[k] - G.lo[k]) * G.scale[k];
+      t = t < 0.f ? 0.f : (t > 15.f ? 15.f : t);
+      cell[k] = (uint32_t)t;
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 3; b >= 0; --b)
+      m = (m << 3) | (((cell[0] >> b) & 1u) << 2) | (((cell[1] >> b) & 1u) << 1) | ((cell[2] >> b) & 1u);
+    const uint32_t oct = (p1.x < 0.f ? 4u : 0u) | (p1.y < 0.f ? 2u : 0u) | (p1.z < 0.f ? 1u : 0u);
+    key = (m << 3) | oct;
+  }
+  keys[i] = key;
+  vals[i] = i;
+}
 
 // Queue entries per thread of the extend and shade stages (a block handles 256 x E pixels,
 // and that is the size of its queue slice).  Brute-force scenes want few, long blocks (8:
@@ -192,6 +225,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene 
   }
   const uint32_t first = blockIdx.x * (256u * kWfETree);
   uint32_t hit_mask = 0, miss_mask = 0;  // bit k: entry k of this thread hit / missed
+  uint32_t entry_pix[kWfETree] = {};     // the pixel of entry k (pixel order, or the regrouped order)
   int k = -1;                            // entry in flight; kWfETree: none left
   bool sample0 = false;
   uint32_t pix = 0;
@@ -237,8 +271,11 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene 
       }
       // the thread's next live pixel, if any
       for (++k; k < kWfETree; ++k) {
-        pix = first + (uint32_t)k * 256u + threadIdx.x;
-        if (pix < n_pixels && V.alive[pix]) break;
+        const uint32_t e = first + (uint32_t)k * 256u + threadIdx.x;
+        if (e >= n_pixels) continue;
+        pix = V.order ? V.order[e] : e;
+        entry_pix[k] = pix;
+        if (V.alive[pix]) break;
       }
       if (k < kWfETree) {
         const float4 p0 = V.P0[pix], p1 = V.P1[pix];
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(256, RT_WF_TREE_WAVES) void k_wf_extend_tree(Scene 
   for (int j = 0; j < kWfETree; ++j) {
     is_hit[j] = (hit_mask >> j) & 1u;
     is_miss[j] = (miss_mask >> j) & 1u;
-    pixk[j] = first + (uint32_t)j * 256u + threadIdx.x;
+    pixk[j] = entry_pix[j];
   }
   uint32_t off[kWfETree];
   uint32_t *slice = V.q + first;
@@ -531,6 +568,10 @@ struct WavefrontState::Impl {
   WfView view{};
   uint32_t *h_counts = nullptr;  // pinned read-back ring
   hipEvent_t ev[8] = {};
+  // regrouping experiment: sort buffers (allocated on first use)
+  char *sort_slab = nullptr;
+  size_t sort_n = 0;
+  uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *sums = nullptr;
 };
 
 static constexpr int kCheckEvery = 4;   // iterations between read-backs of the active count
@@ -539,6 +580,7 @@ static constexpr int kReadbackLag = 1;  // read-backs the host may run ahead of 
 void WavefrontState::release() {
   if (!impl) return;
   if (impl->slab) hipFree(impl->slab);
+  if (impl->sort_slab) hipFree(impl->sort_slab);
   if (impl->h_counts) hipHostFree(impl->h_counts);
   for (auto &e : impl->ev)
     if (e) hipEventDestroy(e);
@@ -589,11 +631,34 @@ static int wf_allocate(WavefrontState::Impl *&impl, size_t n, std::string *err) 
   return 0;
 }
 
+static int regroup_allocate(WavefrontState::Impl *impl, size_t n, std::string *err) {
+  if (impl->sort_slab && impl->sort_n == n) return 0;
+  if (impl->sort_slab) hipFree(impl->sort_slab);
+  impl->sort_slab = nullptr;
+  impl->sort_n = 0;
+  size_t hist = 0, sums = 0;
+  radix_sort_scratch((uint32_t)n, &hist, &sums);
+  const size_t u4 = (n * sizeof(uint32_t) + 255) / 256 * 256;
+  hist = (hist + 255) / 256 * 256;
+  sums = (sums + 255) / 256 * 256;
+  WF_HIP(hipMalloc((void **)&impl->sort_slab, 4 * u4 + hist + sums));
+  char *p = impl->sort_slab;
+  impl->keys[0] = (uint32_t *)p; p += u4;
+  impl->keys[1] = (uint32_t *)p; p += u4;
+  impl->vals[0] = (uint32_t *)p; p += u4;
+  impl->vals[1] = (uint32_t *)p; p += u4;
+  impl->hist = (uint32_t *)p; p += hist;
+  impl->sums = (uint32_t *)p;
+  impl->sort_n = n;
+  return 0;
+}
+
 template <bool STRICT, bool BVH, int EXT, bool APPROX>
-static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const Params &P,
+static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const RegroupGrid *regroup, const Params &P,
                     const Scene &S, uint32_t frame, const Outputs &O, hipStream_t stream,
                     uint32_t *launches, std::string *err) {
-  const WfView &V = impl->view;
+  WfView V = impl->view;
+  V.order = nullptr;
   const uint32_t n = (uint32_t)impl->n_pixels;
   const uint32_t full_blocks = (n + 255u) / 256u;
   constexpr int E = BVH ? kWfETree : kWfEBrute;
@@ -622,9 +687,16 @@ static int wf_frame(WavefrontState::Impl *impl, uint32_t drain_threshold, const 
       *launches += 2;
       break;
     }
-    if constexpr (BVH)
+    if constexpr (BVH) {
+      if (regroup) {
+        hipLaunchKernelGGL(k_wf_keys, dim3(full_blocks), dim3(256), 0, stream, V, n, *regroup, impl->keys[0], impl->vals[0]);
+        WF_HIP(radix_sort_pairs(impl->keys, impl->vals, n, 2, impl->hist, impl->sums, stream));
+        V.order = impl->vals[0];  // two passes: back in the first pair of buffers
+        *launches += 11;
+      }
       hipLaunchKernelGGL((k_wf_extend_tree<APPROX, EXT == kExtDielectric>), dim3(window_blocks), dim3(256), tree_stack_bytes, stream, S, V, slot, n,
                          O.ids);
+    }
     else
       hipLaunchKernelGGL((k_wf_extend<BVH, APPROX, EXT == kExtDielectric>), dim3(window_blocks), dim3(256), 0, stream, S, V, slot, n,
                          O.ids);
@@ -662,6 +734,18 @@ int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &
   }
   int rc = wf_allocate(impl, (size_t)P.width * P.height, err);
   if (rc) return rc;
+  RegroupGrid grid{};
+  const RegroupGrid *use_grid = nullptr;
+  if (regroup && bvh) {
+    rc = regroup_allocate(impl, (size_t)P.width * P.height, err);
+    if (rc) return rc;
+    for (int k = 0; k < 3; ++k) {
+      const float ext = regroup_hi[k] - regroup_lo[k];
+      grid.lo[k] = regroup_lo[k];
+      grid.scale[k] = ext > 0.f ? 16.0f / ext : 0.f;
+    }
+    use_grid = &grid;
+  }
   *launches = 0;
   for (uint32_t fi = 0; fi < F.count; ++fi) {
     const uint32_t frame = F.first + fi * F.stride;
@@ -671,10 +755,10 @@ int WavefrontState::render(bool strict, bool bvh, const Params &P, const Scene &
 #define RT_WF_CASE(n, a, b, e)                                                                              \
   case n:                                                                                                   \
     rc = ext == kExtDielectric                                                                              \
-             ? wf_frame<a, b, kExtDielectric, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err) \
+             ? wf_frame<a, b, kExtDielectric, e>(impl, drain_threshold, use_grid, P, S, frame, O, stream, launches, err) \
          : ext == kExtTexture                                                                               \
-             ? wf_frame<a, b, kExtTexture, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err)  \
-             : wf_frame<a, b, kExtNone, e>(impl, drain_threshold, P, S, frame, O, stream, launches, err);    \
+             ? wf_frame<a, b, kExtTexture, e>(impl, drain_threshold, use_grid, P, S, frame, O, stream, launches, err)  \
+             : wf_frame<a, b, kExtNone, e>(impl, drain_threshold, use_grid, P, S, frame, O, stream, launches, err);    \
     break;
     switch (variant) {
       RT_WF_CASE(0, false, false, false)

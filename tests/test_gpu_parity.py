@@ -1205,6 +1205,32 @@ def test_lbvh_tall_tree_from_clustered_primitives(oracle):
         assert np.array_equal(_bits(got["accum"]), _bits(want["accum"]))
 
 
+def test_wavefront_regrouping_changes_no_bit(monkeypatch):
+    """RT_WF_REGROUP=1 (read when a context is created): the wavefront pipeline sorts the live pixels by the
+    cell and direction octant of their rays before every extend stage of an LBVH scene.  Path state stays
+    indexed by pixel, so every output is the one of the pixel-order pipeline, bit for bit."""
+    w, h = 200, 120
+    sph, ior = rt.grid_spheres_scene_glass(600)
+
+    def run(flags):
+        with rt.Renderer(w, h, mode=rt.MODE_WAVEFRONT, flags=flags | rt.FLAG_FORCE_BVH) as r:
+            r.set_params(rt.make_ubo(w, h, 3, 9))
+            r.set_spheres(sph)
+            r.set_dielectric(ior)
+            r.render(1, 2, 1)
+            return r.read_accum(), r.read_rgba8(), r.read_primary_ids(), int(r.stats().rays), r.stats().last_launches
+
+    for flags in (0, rt.FLAG_STRICT_MATH):
+        monkeypatch.setenv("RT_WF_REGROUP", "0")
+        monkeypatch.setenv("RT_WF_DRAIN_THRESHOLD", "0")          # stay in the staged pipeline to the end
+        plain = run(flags)
+        monkeypatch.setenv("RT_WF_REGROUP", "1")
+        sorted_ = run(flags)
+        assert sorted_[4] > plain[4]                               # the sort's launches were there
+        assert np.array_equal(_bits(np.nan_to_num(plain[0])), _bits(np.nan_to_num(sorted_[0])))
+        assert np.array_equal(plain[1], sorted_[1]) and np.array_equal(plain[2], sorted_[2]) and plain[3] == sorted_[3]
+
+
 def test_lbvh_too_tall_falls_back_to_brute_force_and_says_so(oracle, monkeypatch):
     """A tree taller than the traversal stack (64 levels; RT_BVH_MAX_HEIGHT lowers the limit for this
     test) is not an error: the scene is traced by brute force, rt_stats.bvh_fallback says so,
