@@ -270,6 +270,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
   // heaviest tiles run as sparse waves, large batches for everything else win: 1920x1080 1.156 ->
   // 1.117 ms, and 1.105 with a chain share of 1/128 instead of 1/32.)
   constexpr bool kGroupedFetch = RT_BATCH_GROUPED != 0 && FORM == kRegenBatched && !BVH;
+  constexpr bool kSmall = FORM != kRegenBatched;  // straight-line search for scenes of <= 4 spheres (see closest_hit_brute)
   constexpr int SHADE_BATCH = FORM != kRegenPlain ? RT_REGEN_SHADE_BATCH : 1;
   constexpr int END_BATCH = FORM != kRegenPlain ? RT_REGEN_END_BATCH : 8;
   constexpr int BLOCK = BVH ? 256 : kTileBlock;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
         pending.cx = pending.cy = pending.cz = 0.0f;
         while (true) {
           if (ended == 0 && pending.idx < 0) {
-            const Hit h = closest_hit<BVH, APPROX, kGroupedFetch, DIEL>(S, o, d, stack, skip);
+            const Hit h = closest_hit<BVH, APPROX, kGroupedFetch, DIEL, kSmall>(S, o, d, stack, skip);
             ++nrays;
             RT_STORE_FIRST_ID(h.idx);
             if (h.idx >= 0) pending = h;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(BVH ? 256 : kTileBlock, regen_waves(STRICT, EXT != 
       uchar4 img = O.rgba8[pix];
       bool active = true;
       while (active) {
-        Hit h = closest_hit<BVH, APPROX, CHAIN, DIEL>(S, o, d, stack, skip);
+        Hit h = closest_hit<BVH, APPROX, CHAIN, DIEL, kSmall>(S, o, d, stack, skip);
         ++nrays;
         if (s == 0 && b == 0) id0 = h.idx;
         bool path_done;

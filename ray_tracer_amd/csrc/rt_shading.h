@@ -208,7 +208,7 @@ struct Closest<false> {
     best.cx = best.cy = best.cz = 0.0f;
     best_n = __builtin_inff();
   }
-  template <bool LIKELY = false>
+  template <bool LIKELY = false, bool FAR = false, bool SELECT = false>
   __device__ __forceinline__ void sphere(float4 g, int idx, f3 o, f3 d, float a) {
     sphere_candidate_tie(g, idx, o, d, a, best_n, best);
   }
@@ -248,7 +248,10 @@ struct Closest<true> {
   // FAR: the far root, numerator -bh + sqrt(disc) (no early rejection on the sign of bh).
   // LIKELY: the caller expects most tests to find the sphere in front of the ray (code
   // layout only)
-  template <bool LIKELY = false, bool FAR = false>
+  // SELECT: the update as selects behind one three-way classification instead of nested exec-mask
+  // regions (fewer scalar instructions and branches per test; it pays in the plain and mixed forms of
+  // k_mega_regen, 1920x1080 1.040 -> 1.024 ms, and costs the register-capped batched kernel 0.6 %)
+  template <bool LIKELY = false, bool FAR = false, bool SELECT = false>
   __device__ __forceinline__ void sphere(float4 g, int i, f3 o, f3 d, float a) {
     f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
     const float cbh = dot(oc, d);
@@ -260,6 +263,33 @@ struct Closest<true> {
       // E plus a floor that keeps denormal-small numerators out of the shortcuts
       const float cerr = __builtin_fmaf(4.76837158e-7f, FAR ? s + __builtin_fabsf(cbh) : s - cbh, 1e-20f);
       const float band = cerr + err;
+      if constexpr (SELECT) {
+      // accepted outright / rejected outright / too close to call, then ONE set of selects
+      bool accept = cn > cerr && cn < n - band;
+      const bool unsure = !accept && !(cn < -cerr || cn > n + band);
+      if (__builtin_expect(unsure, 0)) {
+        const float ne = FAR ? -cbh + ieee_sqrt(cdisc) : -cbh - ieee_sqrt(cdisc);
+        if (ne > -1e-30f) {
+          const float qe = ieee_div(ne, a);
+          if (qe >= 0.0f) {
+            accept = true;
+            if (idx != kNoHit) {
+              const float qb = ieee_div(-bh + sgn * ieee_sqrt(disc), a);
+              accept = qe < qb || (qe == qb && i < idx);
+            }
+          }
+        }
+      }
+      n = accept ? cn : n;
+      err = accept ? cerr : err;
+      bh = accept ? cbh : bh;
+      disc = accept ? cdisc : disc;
+      sgn = accept ? (FAR ? 1.0f : -1.0f) : sgn;
+      idx = accept ? i : idx;
+      cx = accept ? g.x : cx;
+      cy = accept ? g.y : cy;
+      cz = accept ? g.z : cz;
+      } else {
       if (cn < -cerr || cn > n + band) return;
       bool accept = cn > cerr && cn < n - band;
       if (__builtin_expect(!accept, 0)) {
@@ -286,6 +316,7 @@ struct Closest<true> {
         cx = g.x;
         cy = g.y;
         cz = g.z;
+      }
       }
     }
   }
@@ -327,13 +358,31 @@ __device__ __forceinline__ SphereGroup load_group(const Scene &S, uint32_t i) {
 
 // GROUPED: spheres are fetched four at a time, for code whose running time is one wave's
 // chain of dependent segments rather than the device's throughput.
-template <bool APPROX, bool GROUPED = false, bool DIEL = false>
+// SMALL: scenes of at most four spheres take the straight-line form below (callers ask for it where it
+// was measured to pay: the plain and mixed forms of k_mega_regen; 1920x1080 1.065 -> 1.044 ms, whereas the
+// batched-throughout launch of 3840x2160 lost 1.2 % with it).
+template <bool APPROX, bool GROUPED = false, bool DIEL = false, bool SMALL = false>
 __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int skip) {
   const float a = dot(d, d);
   Closest<APPROX> C;
   C.reset(a);
   const uint32_t n = S.n_spheres;
-  if constexpr (GROUPED) {
+  // At most four spheres (the reference's own scene has three): ONE 64-byte scalar fetch and one
+  // wave-uniform jump into a straight line of tests, instead of a loop whose bookkeeping (index,
+  // bound check, address) is ~10 scalar instructions and a taken branch per sphere.  The tests run
+  // from the highest index down; the winner does not depend on the order (ties go to the lower index
+  // by the rule in Closest, not by visiting order).
+  if (SMALL && !DIEL && n <= 4u) {
+    if (n) {
+      const SphereGroup G = load_group(S, 0);
+      switch (n) {
+        case 4: C.template sphere<true, false, true>(G.g3, 3, o, d, a); [[fallthrough]];
+        case 3: C.template sphere<true, false, true>(G.g2, 2, o, d, a); [[fallthrough]];
+        case 2: C.template sphere<true, false, true>(G.g1, 1, o, d, a); [[fallthrough]];
+        default: C.template sphere<true, false, true>(G.g0, 0, o, d, a);
+      }
+    }
+  } else if constexpr (GROUPED) {
     // Each step is one 64-byte scalar fetch and the loop bookkeeping is paid once per four
     // tests: 7 % off the chain of a wave that runs alone, nothing for a device full of waves
     // (which hide the bookkeeping behind each other's arithmetic).
@@ -345,14 +394,14 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int
         for (uint32_t k = 0; k < 4u; ++k) {
           if (i + k >= n) break;
           if ((int)(i + k) == skip) C.sphere_far(g[k], (int)(i + k), o, d, a);
-          else C.template sphere<true>(g[k], (int)(i + k), o, d, a);
+          else C.template sphere<true, false, SMALL>(g[k], (int)(i + k), o, d, a);
         }
         continue;
       }
-      C.template sphere<true>(G.g0, (int)i, o, d, a);
-      if (i + 1u < n) C.template sphere<true>(G.g1, (int)(i + 1u), o, d, a);
-      if (i + 2u < n) C.template sphere<true>(G.g2, (int)(i + 2u), o, d, a);
-      if (i + 3u < n) C.template sphere<true>(G.g3, (int)(i + 3u), o, d, a);
+      C.template sphere<true, false, SMALL>(G.g0, (int)i, o, d, a);
+      if (i + 1u < n) C.template sphere<true, false, SMALL>(G.g1, (int)(i + 1u), o, d, a);
+      if (i + 2u < n) C.template sphere<true, false, SMALL>(G.g2, (int)(i + 2u), o, d, a);
+      if (i + 3u < n) C.template sphere<true, false, SMALL>(G.g3, (int)(i + 3u), o, d, a);
     }
   } else {
     // The scene is read-only for the whole launch.  Reading it through the constant address
@@ -365,7 +414,7 @@ __device__ __forceinline__ Hit closest_hit_brute(const Scene &S, f3 o, f3 d, int
     for (uint32_t i = 0; i < n; ++i) {
       const float4 g_next = load_const(geom + (i + 1u < n ? i + 1u : i));
       if (DIEL && (int)i == skip) C.sphere_far(g, (int)i, o, d, a);
-      else C.sphere(g, (int)i, o, d, a);
+      else C.template sphere<false, false, SMALL>(g, (int)i, o, d, a);
       g = g_next;
     }
   }

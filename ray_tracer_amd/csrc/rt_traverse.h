@@ -154,10 +154,10 @@ __device__ __forceinline__ Hit closest_hit_bvh(const Scene &S, f3 o, f3 d, int *
 }
 
 // closest hit through whichever structure the kernel was built for
-template <bool BVH, bool APPROX, bool GROUPED = false, bool DIEL = false>
+template <bool BVH, bool APPROX, bool GROUPED = false, bool DIEL = false, bool SMALL = false>
 __device__ __forceinline__ Hit closest_hit(const Scene &S, f3 o, f3 d, int *stack, int skip) {
   if constexpr (BVH) return closest_hit_bvh<false, APPROX, DIEL>(S, o, d, stack, skip);
-  else return closest_hit_brute<APPROX, GROUPED, DIEL>(S, o, d, skip);
+  else return closest_hit_brute<APPROX, GROUPED, DIEL, SMALL>(S, o, d, skip);
 }
 
 // ---- a search whose state outlives the loop iteration ----------------------------------
