@@ -250,7 +250,11 @@ __device__ __forceinline__ int wave_count(bool p) {
 #define RT_SPARSE_FEW_TILES 4096  // 1280x720 has 3,600 tiles, 1920x1080 8,160
 #endif
 // waves per SIMD a form is compiled for (the register budget follows from it)
+#ifndef RT_REGEN_MIXED_WAVES
+#define RT_REGEN_MIXED_WAVES RT_MEGA_WAVES
+#endif
 constexpr int regen_waves(bool strict, bool tex, int form) {
+  if (form == kRegenMixed && !strict && !tex) return RT_REGEN_MIXED_WAVES;
   if (form != kRegenBatched || strict) return RT_MEGA_WAVES;
   return tex ? RT_REGEN_BATCHED_TEX_WAVES : RT_REGEN_BATCHED_WAVES;
 }
