@@ -392,6 +392,37 @@ def case_emission_digits():
     return c
 
 
+def case_exact_ties():
+    """`if (hitInfo.didHit && hitInfo.dst < closestHit.dst)`, ray_tracing.comp:183: among spheres at the
+    same distance the strict < keeps the first in index order.  Records with identical geometry give
+    bit-identical distances in ANY evaluation, so the answer needs no arithmetic: the scene is the
+    emission-digit scene with spheres repeated under other indices and other digits (indices 1 and 4
+    are one ball, 2 and 6 another, 3 / 5 / 7 a third, in orders that put the brighter copy first in one
+    group and last in another); every pixel shows the digits of the LOWEST index of its group."""
+    ubo = make_ubo(800, 600, 1, 1, ground=(0, 0, 0), horizon=(0, 0, 0), zenith=(0, 0, 0))
+    balls = {"a": ((0, 0, -5), 1), "b": ((3, 0, -5), 1), "c": ((-2.5, 0.5, -4), 0.75), "ground": ((0, -101, -5), 100)}
+    order = ["ground", "a", "b", "c", "a", "c", "b", "c"]
+    digits = [(7, 9, 11), (20, 200, 40), (250, 3, 90), (60, 61, 62), (240, 10, 220), (5, 250, 5), (1, 2, 3), (99, 98, 97)]
+    full = np.stack([sphere(*balls[k], (0.5, 0.5, 0.5), emission=[(v / 255.0) ** 2 for v in dg], strength=1.0)
+                     for k, dg in zip(order, digits)])
+    first_of = {}
+    for i, k in enumerate(order):
+        first_of.setdefault(k, i)
+    unique = sorted(first_of.values())                                 # [0, 1, 2, 3]
+    pix = [(x, y) for y in range(150, 420, 9) for x in range(60, 760, 9)]
+    c = deterministic_case("exact_ties_lowest_index", "172-190", case_exact_ties.__doc__, ubo, full[unique],
+                           800, 608, pix, tol=BASE_TOL)
+    seen = set()
+    for r in c["pixels"]:
+        if r["id"] >= 0:
+            r["id"] = unique[r["id"]]
+            assert r["rgba8"] == list(digits[r["id"]]) + [255], r
+            seen.add(r["id"])
+    assert seen == set(unique), seen
+    c["spheres"] = [[float(v) for v in sp] for sp in full]
+    return c
+
+
 def case_constant_radiance():
     """ground = horizon = zenith = c makes the environment the constant c; a lone convex sphere cannot
     be hit twice (near root only, scattered directions point outwards), so EVERY path through an
@@ -609,6 +640,28 @@ def case_blend():
                 accum_sum=[float(sum(s[ch] for s in seen)) for ch in range(3)], tol=BASE_TOL)
 
 
+def case_blend_clamp():
+    """Where the clamp sits, ray_tracing.comp:103-109: the old texel comes back from the rgba8 image
+    (<= 1), the new colour enters the weighted sum unclamped, and the store clamps the result.  Frame 0
+    stores a colour of (2, 0.6, 3) as (255, 153, 255); frame 1 adds (0.2, 0.6, 0.2) at weight 1/2:
+    (1 + 0.2) / 2 = 0.6 -> 153 (an unclamped old value would give 1.1 -> 255); frame 2 adds (4, 0.6, 0.15)
+    at weight 1/3: 0.6 * 2/3 + 4/3 > 1 -> 255 (a new colour clamped before the sum would give 187)."""
+    ubo = make_ubo(800, 600, 1, 1, ground=(0, 0, 0), horizon=(0, 0, 0), zenith=(0, 0, 0))
+    gammas = [(2.0, 0.6, 3.0), (0.2, 0.6, 0.2), (4.0, 0.6, 0.15)]
+    frames = [0, 1, 2]
+    emissions = [[g * g for g in row] for row in gammas]
+    seen = [[math.sqrt(lit(e)) for e in row] for row in emissions]
+    history = blend_by_hand(seen, frames)
+    assert history is not None
+    assert history[0] == [255, 153, 255, 255] and history[1][0] == 153 and history[2][0] == 255, history
+    steps = [dict(frame=f, sphere0_emission=[float(np.float32(v)) for v in e], rgba8_after=texel,
+                  frame_colour=[float(v) for v in g]) for e, f, texel, g in zip(emissions, frames, history, seen)]
+    return dict(name="eight_bit_blend_clamps_at_the_store", kind="blend", shader_lines="103-109",
+                note=case_blend_clamp.__doc__, width=800, height=608, ubo=[float(v) for v in ubo],
+                spheres=[[float(v) for v in sp] for sp in default_spheres()], x=400, y=300, steps=steps,
+                accum_sum=[float(sum(st[ch] for st in seen)) for ch in range(3)], tol=BASE_TOL)
+
+
 def lobe_mean(n, ubo, grid=1800):
     """E[env(normalize(n + u))] and its per-sample variance for u uniform on the unit sphere --
     the distribution of `normalize(normal + randomDirection)`, ray_tracing.comp:127-132,202
@@ -699,10 +752,11 @@ def case_statistical():
 
 def main():
     cases = [case_environment(), case_environment_rotated(), case_default_scene_sky(), case_mirror(),
-             case_mirror_chain(), case_emission_order(), case_emission_digits()]
+             case_mirror_chain(), case_emission_order(), case_emission_digits(), case_exact_ties()]
     cases += case_constant_radiance()
     cases += [case_replay_lone_sphere(), case_replay_default_scene()]
     cases.append(case_blend())
+    cases.append(case_blend_clamp())
     cases += case_statistical()
     for c in cases:                       # rows -> columns: a third of the bytes
         if "pixels" in c:

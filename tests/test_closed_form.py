@@ -68,9 +68,13 @@ def test_oracle_deterministic_radiance(oracle, name, math):
     assert r["rays"] == sum(c["pixels"]["segments"])
 
 
-def test_oracle_eight_bit_blend_by_hand(oracle):
+BLENDS = sorted(n for n, c in CASES.items() if c["kind"] == "blend")
+
+
+@pytest.mark.parametrize("name", BLENDS)
+def test_oracle_eight_bit_blend_by_hand(oracle, name):
     """ray_tracing.comp:103-109: each launch continues the rgba8 image of the one before."""
-    c = CASES["eight_bit_blend_by_hand"]
+    c = CASES[name]
     ubo, sph = case_inputs(c)
     pix = np.array([c["y"] * c["width"] + c["x"]], dtype=np.uint32)
     accum = np.zeros((1, 4), np.float32)
@@ -83,7 +87,7 @@ def test_oracle_eight_bit_blend_by_hand(oracle):
         assert r["rgba8"][0].tolist() == step["rgba8_after"], (step["frame"], r["rgba8"][0])
     want = np.array(c["accum_sum"])
     assert np.all(np.abs(accum[0, :3] - want) <= c["tol"]["abs"] * 4 + c["tol"]["rel"] * want * 4)
-    assert accum[0, 3] == 4
+    assert accum[0, 3] == len(c["steps"])
 
 
 def check_statistical(c, accum):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import ray_tracer_amd as rt
-from test_closed_form import (CASES, DETERMINISTIC, STATISTICAL, case_inputs, check_deterministic,
+from test_closed_form import (BLENDS, CASES, DETERMINISTIC, STATISTICAL, case_inputs, check_deterministic,
                               check_statistical, pixel_list)
 
 pytestmark = pytest.mark.gpu
@@ -69,9 +69,11 @@ def test_fast_kernels_against_closed_form(name, mode):
 
 
 @pytest.mark.parametrize("flags", [rt.FLAG_STRICT_MATH, 0])
-def test_eight_bit_blend_by_hand(flags):
-    """ray_tracing.comp:103-109 with a scene edited between launches; frame 600 shows the stall."""
-    c = CASES["eight_bit_blend_by_hand"]
+@pytest.mark.parametrize("name", BLENDS)
+def test_eight_bit_blend_by_hand(name, flags):
+    """ray_tracing.comp:103-109 with a scene edited between launches; frame 600 shows the stall, the
+    second case where the clamp sits."""
+    c = CASES[name]
     ubo, sph = case_inputs(c)
     with rt.Renderer(c["width"], c["height"], flags=flags) as r:
         r.set_params(ubo)
@@ -85,7 +87,7 @@ def test_eight_bit_blend_by_hand(flags):
         accum = r.read_accum()[c["y"], c["x"]]
     want = np.array(c["accum_sum"])
     assert np.all(np.abs(accum[:3] - want) <= 1e-6 * (1 + want))
-    assert accum[3] == 4
+    assert accum[3] == len(c["steps"])
 
 
 @pytest.mark.parametrize("flags", [rt.FLAG_STRICT_MATH, 0])
