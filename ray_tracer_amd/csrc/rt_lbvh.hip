@@ -42,6 +42,7 @@
 #include "rt_lbvh.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -188,6 +189,12 @@ __global__ __launch_bounds__(kThreads) void k_leaf_boxes(const float4 *__restric
   }
 }
 
+// cbounds: [0..2] running minima (ordered-uint form, start at the top), [3..5] running maxima,
+// [64..127] the refit's words of meta
+__global__ void k_build_init(uint32_t *cbounds) {
+  cbounds[threadIdx.x] = threadIdx.x < 3u ? 0xffffffffu : 0u;
+}
+
 #ifndef RT_MORTON_ADAPTIVE
 #define RT_MORTON_ADAPTIVE 1  // 0: ten bits per axis on cubic cells
 #endif
@@ -251,13 +258,6 @@ __global__ __launch_bounds__(kThreads) void k_rs_hist(const uint32_t *__restrict
   hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];  // digit-major: scan order
 }
 
-// Exclusive scan of `total` counters in place.  Three launches: every block sums its tile of
-// 2048 counters (coalesced), one block scans the tile sums, every block scans its tile on
-// top of its sum.  (One block walking all 256 * blocks counters took 0.2 ms per radix pass
-// for a million keys, half of the whole build.)
-constexpr uint32_t kScanE = 8;
-constexpr uint32_t kScanTile = kThreads * kScanE;
-
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
   const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
@@ -268,66 +268,30 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
   return v;
 }
 
-__global__ __launch_bounds__(kThreads) void k_scan_reduce(const uint32_t *__restrict__ data, uint32_t total,
-                                                          uint32_t *__restrict__ tile_sum) {
+// The radix passes' own scan, in one launch: block d turns row d of the digit-major histogram (the
+// counts of digit d in blocks 0, 1, ...) into its exclusive prefix, in place, and leaves the row's total
+// in totals[d]; k_rs_scatter adds the 256 totals up by itself.  (A general exclusive scan of all
+// 256 x blocks counters -- tile sums, a scan of those, tiles again: three launches -- cost a radix pass
+// 10 of its 29 microseconds at a million keys.)
+__global__ __launch_bounds__(kThreads) void k_scan_rows(uint32_t *__restrict__ hist, uint32_t nblk,
+                                                        uint32_t *__restrict__ totals) {
   __shared__ uint32_t wsum[kThreads / 64];
-  const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanE;
+  uint32_t *row = hist + (size_t)blockIdx.x * nblk;
+  const uint32_t per = (nblk + kThreads - 1u) / kThreads;
+  const uint32_t b = min(threadIdx.x * per, nblk), e = min(b + per, nblk);
   uint32_t sum = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < kScanE; ++k) sum += first + k < total ? data[first + k] : 0u;
+  for (uint32_t i = b; i < e; ++i) sum += row[i];
   const uint32_t inc = wave_inclusive_scan(sum);
   if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int wv = 0; wv < kThreads / 64; ++wv) t += wsum[wv];
-    tile_sum[blockIdx.x] = t;
-  }
-}
-
-// exclusive scan of a short array in place, one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *data, uint32_t total) {
-  __shared__ uint32_t part[1024];
-  const uint32_t per = (total + 1023u) / 1024u;
-  const uint32_t b = threadIdx.x * per, e = min(b + per, total);
-  uint32_t sum = 0;
-  for (uint32_t i = b; i < e; ++i) sum += data[i];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024u; off <<= 1) {
-    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
+  uint32_t run = inc - sum;
+  for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) run += wsum[wv];
   for (uint32_t i = b; i < e; ++i) {
-    const uint32_t c = data[i];
-    data[i] = run;
+    const uint32_t c = row[i];
+    row[i] = run;
     run += c;
   }
-}
-
-__global__ __launch_bounds__(kThreads) void k_scan_apply(uint32_t *__restrict__ data, uint32_t total,
-                                                         const uint32_t *__restrict__ tile_sum) {
-  __shared__ uint32_t wsum[kThreads / 64];
-  const uint32_t first = blockIdx.x * kScanTile + threadIdx.x * kScanE;
-  uint32_t c[kScanE], sum = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < kScanE; ++k) {
-    c[k] = first + k < total ? data[first + k] : 0u;
-    sum += c[k];
-  }
-  const uint32_t inc = wave_inclusive_scan(sum);
-  if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  uint32_t run = tile_sum[blockIdx.x] + inc - sum;
-  for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) run += wsum[wv];
-#pragma unroll
-  for (uint32_t k = 0; k < kScanE; ++k) {
-    if (first + k < total) data[first + k] = run;
-    run += c[k];
-  }
+  if (threadIdx.x == kThreads - 1) totals[blockIdx.x] = run;
 }
 
 __global__ __launch_bounds__(kThreads) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
@@ -336,11 +300,21 @@ __global__ __launch_bounds__(kThreads) void k_rs_scatter(const uint32_t *__restr
                                                          uint32_t *__restrict__ vals_out, uint32_t n,
                                                          uint32_t shift,
                                                          const uint32_t *__restrict__ hist,
+                                                         const uint32_t *__restrict__ totals,
                                                          uint32_t nblk) {
   __shared__ uint32_t base[256];       // next output slot of each digit for this block
   __shared__ uint32_t wcount[4][256];  // per wave, keys of each digit in the current round
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  base[t] = hist[t * nblk + blockIdx.x];
+  {  // keys of smaller digits anywhere (exclusive scan of the 256 totals) + keys of this digit in earlier blocks
+    const uint32_t mine = totals[t];
+    const uint32_t inc = wave_inclusive_scan(mine);
+    if (lane == 63u) wcount[0][wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - mine;
+    for (uint32_t w = 0; w < wave; ++w) before += wcount[0][w];
+    __syncthreads();
+    base[t] = before + hist[t * nblk + blockIdx.x];
+  }
   const uint32_t first = blockIdx.x * kRsTile;
   for (int k = 0; k < kRsE; ++k) {
     wcount[0][t] = 0; wcount[1][t] = 0; wcount[2][t] = 0; wcount[3][t] = 0;
@@ -473,6 +447,9 @@ __device__ __forceinline__ void finish_node(const RefitView &v, int i, int c0, i
   v.stamp[i] = pass;
 }
 
+#ifndef RT_REFIT_MID_SHIFT
+#define RT_REFIT_MID_SHIFT 16   // the second refit launch works on tiles of 2^16 sorted positions
+#endif
 constexpr int kRefitTile = 2048;                     // sorted positions (and node indices) per block of k_refit_local
 constexpr int kRefitThreads = 1024;
 constexpr int kRefitE = kRefitTile / kRefitThreads;  // nodes per thread
@@ -481,17 +458,47 @@ constexpr int kTopE = kTopCap / 1024;
 constexpr uint32_t kTopPassBase = 0x01000000u;       // slow path: its rounds are numbered from here (above any local round)
 constexpr uint32_t kListedBit = 0x80000000u;         // stamp of a listed node until it is finished: this bit | its slot
 
-// A child as its parent sees it while the parent waits: `wait` >= 0 is the LDS slot of a child that the
-// same kernel has yet to finish (its box is read from LDS then), -1 a child whose box is already here.
-struct PendingChild {
-  int ref;        // what the parent's record will hold: node index, leaf reference or kNullLeaf
-  int wait;
-  bool folded;    // an internal child of at most kLeafMaxPrims primitives: referenced as a leaf, height 0
-  float lo[3], hi[3], height;
+// ---- bounds, bottom-up, without rounds -------------------------------------------------------
+// Inside one block the classic scheme works on LDS alone: a walk starts at a leaf and climbs; at every
+// node it publishes what it carries (the box, height and reference of the child it comes from) in the
+// walk's own LDS slot and then swaps a token naming that slot into the node's word.  The walk that finds
+// the word empty stops there; the one that finds a token is the second to arrive, reads the other child
+// from the slot the token names, writes the node's record and climbs on with the union.  Nobody waits
+// for anybody, and the only memory the hand-off goes through is the block's own LDS (DS operations of a
+// wave execute in order, so a slot is complete before its token can be seen).  Blocks never hand
+// anything to each other inside a launch: what crosses a block's boundary is left to the next launch.
+struct Carried {
+  float lo[3], hi[3];
+  float height;   // as the parent counts it: 0 for a leaf and for a subtree referenced as one leaf
+  int ref;        // what the parent's record holds: node index, leaf reference or kNullLeaf
 };
+constexpr uint32_t kTokenSide = 0x80000000u;
 
-__device__ __forceinline__ void write_node(const RefitView &v, int i, const PendingChild &a, const PendingChild &b,
-                                           float box[7]) {
+template <int CAP>
+__device__ __forceinline__ void publish_slot(float (&pub)[8][CAP], uint32_t slot, const Carried &c) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    pub[q][slot] = c.lo[q];
+    pub[3 + q][slot] = c.hi[q];
+  }
+  pub[6][slot] = c.height;
+  pub[7][slot] = __int_as_float(c.ref);
+}
+template <int CAP>
+__device__ __forceinline__ Carried read_slot(const float (&pub)[8][CAP], uint32_t slot) {
+  Carried c;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    c.lo[q] = pub[q][slot];
+    c.hi[q] = pub[3 + q][slot];
+  }
+  c.height = pub[6][slot];
+  c.ref = __float_as_int(pub[7][slot]);
+  return c;
+}
+// record of node i from its two children (a = child 0); returns the node's box and true height
+__device__ __forceinline__ void write_record(const RefitView &v, int i, const Carried &a, const Carried &b,
+                                             float box[7]) {
   float4 *out = (float4 *)(v.nodes + i);
   out[0] = make_float4(a.lo[0], a.lo[1], a.lo[2], __int_as_float(a.ref));
   out[1] = make_float4(a.hi[0], a.hi[1], a.hi[2], __int_as_float(0));
@@ -505,145 +512,137 @@ __device__ __forceinline__ void write_node(const RefitView &v, int i, const Pend
   box[6] = fmaxf(a.height, b.height) + 1.f;
 }
 
-// meta: [0] number of listed nodes, [1] height of the tree, [2] 1 once the root is finished, [3] rounds of k_refit_top
-__global__ __launch_bounds__(kRefitThreads) void k_refit_local(RefitView v, uint32_t *__restrict__ top_list,
+// One walk: `c` arrives at the node of local index `cur` from side `side`.  node_of(cur) is the node's
+// global index, ref_self[cur] the reference its parent holds for it (itself, or a leaf reference when
+// it is folded), parent[cur] its parent's local index | side << 15, or 0xffff when the parent is not
+// this block's.  Every node a walk finishes gets its record; those without a parent here (all of them
+// with all_boxes) also get their box and a stamp, which the next launch reads.
+// The walk takes at most max_steps nodes; returns true when it is still going then (cur, side and c say
+// where it stands: arriving, nothing published yet).  A wave keeps looping while any of its lanes
+// climbs, and the walks thin out by half per level, so the callers cut the climbs short, gather the
+// survivors into the block's first waves and let those finish: a third of the instructions.
+template <int CAP, typename NodeOf>
+__device__ __forceinline__ bool climb(const RefitView &v, float (&pub)[8][CAP], uint32_t *token,
+                                      const unsigned short *parent, const int *ref_self, NodeOf node_of,
+                                      uint32_t my_slot, uint32_t &cur, uint32_t &side, Carried &c, bool all_boxes,
+                                      uint32_t max_steps, uint32_t *root_out = nullptr) {
+  for (uint32_t step = 0; step < max_steps; ++step) {
+    // (The LDS operations of a wave execute in the order they are issued, so the slot is written before
+    // the swap and read after it; the compiler must keep that order too.  A fence proper would also wait
+    // for the wave's global stores, a memory round trip per level of the climb.)
+    publish_slot(pub, my_slot, c);
+    const uint32_t up = parent[cur];     // (read here, so that they travel with the swap instead of after it)
+    const int self = ref_self[cur];
+    asm volatile("" ::: "memory");
+    const uint32_t mine = (my_slot + 1u) | (side ? kTokenSide : 0u);
+    const uint32_t old = atomicCAS(&token[cur], 0u, mine);
+    asm volatile("" ::: "memory");
+    if (old == 0u) return false;   // first to arrive: the other child's walk finishes this node
+    const Carried other = read_slot(pub, (old & ~kTokenSide) - 1u);
+    const int i = node_of(cur);
+    float box[7];
+    if (side) write_record(v, i, other, c, box);
+    else write_record(v, i, c, other, box);
+    if (all_boxes || up == 0xffffu) {
+      v.box_lo[i] = make_float4(box[0], box[1], box[2], box[6]);
+      v.box_hi[i] = make_float4(box[3], box[4], box[5], 0.f);
+      v.stamp[i] = 1u;
+    }
+    if (i == 0 && root_out) {
+      root_out[1] = (uint32_t)box[6];
+      root_out[0] = 1u;
+    }
+    if (up == 0xffffu) return false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      c.lo[k] = box[k];
+      c.hi[k] = box[3 + k];
+    }
+    c.ref = self;
+    c.height = c.ref < 0 ? 0.f : box[6];
+    cur = up & 0x7fffu;
+    side = up >> 15;
+  }
+  return true;
+}
+#ifndef RT_REFIT_FIRST_STEPS
+#define RT_REFIT_FIRST_STEPS 5   // nodes a leaf's walk takes before the survivors are gathered
+#endif
+
+// meta: [0] number of listed nodes, [1] height of the tree, [2] 1 once the root is finished, [3] rounds of the slow path
+// A listed node: its index and its run of sorted positions, so that the launches that pick nodes off the
+// list by their runs read the list and nothing else.
+__global__ __launch_bounds__(kRefitThreads) void k_refit_local(RefitView v, uint4 *__restrict__ top_list,
                                                                uint32_t *meta) {
-  __shared__ float leaf_b[6][kRefitTile];           // boxes of the tile's leaves
-  __shared__ unsigned char leaf_null[kRefitTile];   // leaf of an oversized sphere (kept out of the tree)
-  __shared__ float node_b[7][kRefitTile];           // boxes and heights of the tile's finished nodes
-  __shared__ unsigned short node_round[kRefitTile]; // round in which a node was finished, 0: not yet
-  __shared__ unsigned char has_parent[kRefitTile];  // its parent lies inside the tile too
-  __shared__ uint32_t n_listed, list_base;
-  __shared__ int moved[3];                          // "a node was finished in round r" at [r % 3]
+  __shared__ float pub[8][kRefitTile];                // one slot per leaf = per walk
+  __shared__ uint32_t token[kRefitTile];              // per node: 0, or the slot + 1 (| side) of the child that arrived first
+  __shared__ unsigned short parent[kRefitTile];       // per node: parent's local index | side << 15, 0xffff: not in this tile
+  __shared__ unsigned short leaf_parent[kRefitTile];  // the same per leaf
+  __shared__ int ref_self[kRefitTile];                // per node: the reference its parent's record holds
+  __shared__ uint32_t queue[kRefitTile];              // walks that go on after their first steps: slot | node << 11 | side << 22
+  __shared__ uint32_t n_listed, list_base, n_queued;
+  static_assert(kRefitTile == 2048, "queue entries pack two 11-bit indices");
   const int base = blockIdx.x * kRefitTile;
   const int n_leaves = v.n_internal + 1;
-  if (threadIdx.x == 0) {
-    n_listed = 0;
-    moved[0] = moved[1] = moved[2] = 0;
-  }
+  if (threadIdx.x == 0) n_listed = n_queued = 0;
   for (int p = threadIdx.x; p < kRefitTile; p += kRefitThreads) {
-    node_round[p] = 0;
-    has_parent[p] = 0;
-    if (base + p < n_leaves) {
-      const float4 lo = v.leaf_lo[base + p], hi = v.leaf_hi[base + p];
-      leaf_b[0][p] = lo.x; leaf_b[1][p] = lo.y; leaf_b[2][p] = lo.z;
-      leaf_b[3][p] = hi.x; leaf_b[4][p] = hi.y; leaf_b[5][p] = hi.z;
-      leaf_null[p] = lo.w != 0.f;
-    }
+    token[p] = 0u;
+    parent[p] = 0xffffu;
+    leaf_parent[p] = 0xffffu;
   }
-  // this thread's nodes: inside the tile (todo) or across its boundary (outside)
-  uint32_t todo = 0, outside = 0;
-  int child[kRefitE][2], ref[kRefitE][2];
+  __syncthreads();
+  // this thread's nodes: inside the tile (their whole subtree is) or across its boundary (listed)
+  uint32_t outside = 0;
+  int run_first[kRefitE], run_count[kRefitE];
 #pragma unroll
   for (int k = 0; k < kRefitE; ++k) {
-    const int i = base + k * kRefitThreads + (int)threadIdx.x;
-    child[k][0] = child[k][1] = ref[k][0] = ref[k][1] = 0;
+    const int local = k * kRefitThreads + (int)threadIdx.x;
+    const int i = base + local;
+    run_first[k] = run_count[k] = 0;
     if (i >= v.n_internal) continue;
     const int first = v.range_first[i], count = v.range_count[i];
+    run_first[k] = first;
+    run_count[k] = count;
     if (!(first >= base && first + count <= base + kRefitTile)) {
       outside |= 1u << k;
       continue;
     }
-    todo |= 1u << k;
+    // a small subtree is referenced as one leaf (the root stays a node)
+    ref_self[local] = (i > 0 && count <= kLeafMaxPrims) ? make_leaf_ref((uint32_t)first, (uint32_t)count) : i;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const int c = side ? v.right[i] : v.left[i];
-      child[k][side] = c;
-      ref[k][side] = c;
-      if (c >= 0) {   // a small subtree is referenced as one leaf
-        const int cc = v.range_count[c];
-        if (cc <= kLeafMaxPrims) ref[k][side] = make_leaf_ref((uint32_t)v.range_first[c], (uint32_t)cc);
-      }
+      const unsigned short link = (unsigned short)(local | (side << 15));
+      if (c >= 0) parent[c - base] = link;
+      else leaf_parent[~c - base] = link;
     }
   }
   __syncthreads();
-  const uint32_t inside = todo;
-#pragma unroll
-  for (int k = 0; k < kRefitE; ++k)
-    if (inside & (1u << k)) {
-      if (child[k][0] >= 0) has_parent[child[k][0] - base] = 1;
-      if (child[k][1] >= 0) has_parent[child[k][1] - base] = 1;
-    }
-  // children of node k of this thread, as its record will hold them, from the tile's LDS
-  auto gather = [&](int k, PendingChild pc[2]) {
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int c = child[k][side];
-      if (c < 0) {
-        const int p = ~c - base;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          pc[side].lo[q] = leaf_b[q][p];
-          pc[side].hi[q] = leaf_b[3 + q][p];
-        }
-        pc[side].height = 0.f;
-        pc[side].ref = leaf_null[p] ? kNullLeaf : make_leaf_ref((uint32_t)~c, 1u);
-      } else {
-        const int p = c - base;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          pc[side].lo[q] = node_b[q][p];
-          pc[side].hi[q] = node_b[3 + q][p];
-        }
-        pc[side].ref = ref[k][side];
-        pc[side].height = ref[k][side] < 0 ? 0.f : node_b[6][p];
-      }
-    }
-  };
-  // The rounds touch LDS only (a barrier waits for the wave's outstanding global stores too, and with a
-  // store per finished node every one of ~25 rounds waited a memory round trip); the records go out
-  // to global memory after the last round.
-  for (uint32_t pass = 1;; ++pass) {
-    bool progress = false;
-#pragma unroll
-    for (int k = 0; k < kRefitE; ++k) {
-      if (!(todo & (1u << k))) continue;
-      bool ready = true;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int c = child[k][side];
-        if (c >= 0) {
-          const uint32_t r = node_round[c - base];
-          ready = ready && r != 0u && r < pass;
-        }
-      }
-      if (!ready) continue;
-      PendingChild pc[2];
-      gather(k, pc);
-      const int p = k * kRefitThreads + (int)threadIdx.x;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        node_b[q][p] = fminf(pc[0].lo[q], pc[1].lo[q]);
-        node_b[3 + q][p] = fmaxf(pc[0].hi[q], pc[1].hi[q]);
-      }
-      node_b[6][p] = fmaxf(pc[0].height, pc[1].height) + 1.f;
-      node_round[p] = (unsigned short)pass;
-      todo &= ~(1u << k);
-      progress = true;
-    }
-    // One barrier per round: it orders this round's LDS stores before the next round's loads, and
-    // behind it everyone reads whether anyone moved.  (Three flags in rotation: the one for the next
-    // round is cleared now, while nobody can still be reading it.)
-    if (progress) moved[pass % 3u] = 1;
-    if (threadIdx.x == 0) moved[(pass + 1u) % 3u] = 0;
-    __syncthreads();
-    if (!moved[pass % 3u]) break;
-  }
-  // every node inside the tile is finished now (its whole subtree is inside the tile): the records, and
-  // for the nodes whose parent is not in the tile the box and a stamp, which a later launch reads
+  auto node_of = [&](uint32_t local) { return base + (int)local; };
 #pragma unroll
   for (int k = 0; k < kRefitE; ++k) {
-    if (!(inside & (1u << k))) continue;
-    PendingChild pc[2];
-    gather(k, pc);
-    const int i = base + k * kRefitThreads + (int)threadIdx.x;
-    float box[7];
-    write_node(v, i, pc[0], pc[1], box);
-    if (!has_parent[i - base]) {   // the root of a subtree of this tile: a later launch reads its box
-      v.box_lo[i] = make_float4(box[0], box[1], box[2], box[6]);
-      v.box_hi[i] = make_float4(box[3], box[4], box[5], 0.f);
-      v.stamp[i] = node_round[i - base];
+    const int p = k * kRefitThreads + (int)threadIdx.x;
+    if (base + p >= n_leaves) continue;
+    const uint32_t up = leaf_parent[p];
+    if (up == 0xffffu) continue;   // the leaf's parent straddles the tile: a later launch reads the leaf itself
+    const float4 lo = v.leaf_lo[base + p], hi = v.leaf_hi[base + p];
+    Carried c;
+    c.lo[0] = lo.x; c.lo[1] = lo.y; c.lo[2] = lo.z;
+    c.hi[0] = hi.x; c.hi[1] = hi.y; c.hi[2] = hi.z;
+    c.height = 0.f;
+    c.ref = lo.w != 0.f ? kNullLeaf : make_leaf_ref((uint32_t)(base + p), 1u);
+    uint32_t cur = up & 0x7fffu, side = up >> 15;
+    if (climb(v, pub, token, parent, ref_self, node_of, (uint32_t)p, cur, side, c, false, RT_REFIT_FIRST_STEPS)) {
+      publish_slot(pub, (uint32_t)p, c);   // (nobody reads the slot before a token names it, and none does yet)
+      queue[atomicAdd(&n_queued, 1u)] = (uint32_t)p | (cur << 11) | (side << 22);
     }
+  }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < n_queued; e += kRefitThreads) {
+    const uint32_t entry = queue[e], p = entry & 2047u;
+    uint32_t cur = (entry >> 11) & 2047u, side = entry >> 22;
+    Carried c = read_slot(pub, p);
+    climb(v, pub, token, parent, ref_self, node_of, p, cur, side, c, false, 0xffffffffu);
   }
   // the nodes across the tile's boundary go onto the list
   uint32_t slot = 0;
@@ -656,7 +655,7 @@ __global__ __launch_bounds__(kRefitThreads) void k_refit_local(RefitView v, uint
   for (int k = 0; k < kRefitE; ++k)
     if (outside & (1u << k)) {
       const uint32_t i = (uint32_t)(base + k * kRefitThreads + (int)threadIdx.x);
-      top_list[list_base + slot] = i;
+      top_list[list_base + slot] = make_uint4(i, (uint32_t)run_first[k], (uint32_t)run_count[k], 0u);
       v.stamp[i] = kListedBit | (list_base + slot);
       ++slot;
     }
@@ -681,29 +680,63 @@ __device__ __forceinline__ bool try_finish(const RefitView &v, int i, uint32_t p
 // the same block finishes), fetches the boxes of children that an earlier launch finished, and then
 // runs the rounds on registers and LDS alone.  A block that finds more nodes than it has slots leaves
 // them to the last launch, which falls back to rounds on global memory when it, too, has too many.
-__global__ __launch_bounds__(1024) void k_refit_upper(RefitView v, const uint32_t *__restrict__ top_list,
-                                                      uint32_t *meta, uint32_t tile_shift, uint32_t last) {
-  __shared__ float nb[7][kTopCap];
-  __shared__ unsigned short rnd[kTopCap];
+__global__ __launch_bounds__(1024) void k_refit_upper(RefitView v, const uint4 *__restrict__ top_list,
+                                                      uint32_t *meta, uint32_t tile_shift, uint32_t last,
+                                                      uint32_t earlier_shift, uint32_t cap) {
+  __shared__ float pub[8][kTopCap];            // one slot per picked node (see climb)
+  __shared__ uint32_t token[kTopCap];
+  __shared__ unsigned short parent[kTopCap];   // parent's slot | side << 15, 0xffff: not picked by this block
+  __shared__ int ref_self[kTopCap];
   __shared__ int slot_node[kTopCap];
-  __shared__ uint32_t wave_base[16], n_picked;
-  __shared__ int moved[3];
+  __shared__ unsigned short queue[kTopCap];    // slots of the nodes that start walks
+  __shared__ uint32_t wave_base[16], n_picked, root_seen[2], n_queued;
   const uint32_t n_listed = meta[0];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) moved[0] = moved[1] = moved[2] = 0;
-  // ---- pick: unfinished listed nodes whose run lies in this block's tile, counted, then numbered
-  auto mine = [&](uint32_t j) -> int {
-    if (j >= n_listed) return -1;
-    const int i = (int)top_list[j];
-    if (!(v.stamp[i] & kListedBit)) return -1;   // finished by an earlier launch
-    if (tile_shift < 32u) {
-      const uint32_t first = (uint32_t)v.range_first[i], end = first + (uint32_t)v.range_count[i] - 1u;
-      if ((first >> tile_shift) != blockIdx.x || (end >> tile_shift) != blockIdx.x) return -1;
+  if (threadIdx.x == 0) root_seen[0] = root_seen[1] = n_queued = 0u;
+  // ---- pick: unfinished listed nodes whose run lies in this block's tile, counted, then numbered.
+  // A thread looks at kPickE list entries at a time with the loads of one kind issued together (entry,
+  // stamp, run): three memory round trips per batch instead of three per entry.
+  constexpr int kPickE = 8;
+  // The last launch takes what the launch before it (tiles of 2^earlier_shift positions; 32: there was
+  // none) did not finish: the nodes whose run crosses a boundary of those tiles -- or, when a block of
+  // that launch had more nodes than slots and left them all (meta[4]), whatever still carries a listed stamp.
+  const bool by_stamp = last && earlier_shift < 32u && meta[4] != 0u;
+  auto pick_batch = [&](uint32_t j0, int out[kPickE]) -> uint32_t {
+    uint32_t valid = 0;
+    uint4 e[kPickE];
+#pragma unroll
+    for (int u = 0; u < kPickE; ++u) {
+      const uint32_t j = j0 + (uint32_t)u * 1024u + threadIdx.x;
+      e[u] = j < n_listed ? top_list[j] : make_uint4(0u, 0u, 0u, 1u);
     }
-    return i;
+#pragma unroll
+    for (int u = 0; u < kPickE; ++u) {
+      out[u] = (int)e[u].x;
+      if (e[u].w) continue;   // beyond the list
+      const uint32_t first = e[u].y, end = e[u].y + e[u].z - 1u;
+      bool take;
+      if (!last) take = (first >> tile_shift) == blockIdx.x && (end >> tile_shift) == blockIdx.x;
+      else if (by_stamp) take = true;
+      else take = earlier_shift >= 32u || (first >> earlier_shift) != (end >> earlier_shift);
+      if (take) valid |= 1u << u;
+    }
+    if (by_stamp) {
+      uint32_t st[kPickE];
+#pragma unroll
+      for (int u = 0; u < kPickE; ++u) st[u] = (valid >> u) & 1u ? v.stamp[out[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < kPickE; ++u)
+        if (!(st[u] & kListedBit)) valid &= ~(1u << u);   // finished by the earlier launch
+    }
+    return valid;
   };
-  uint32_t count = 0;
-  for (uint32_t j0 = 0; j0 < n_listed; j0 += 1024u) count += mine(j0 + threadIdx.x) >= 0 ? 1u : 0u;
+  int first_batch[kPickE];
+  const uint32_t first_valid = pick_batch(0u, first_batch);   // kept: most builds have no second batch
+  uint32_t count = (uint32_t)__builtin_popcount(first_valid);
+  for (uint32_t j0 = kPickE * 1024u; j0 < n_listed; j0 += kPickE * 1024u) {
+    int tmp[kPickE];
+    count += (uint32_t)__builtin_popcount(pick_batch(j0, tmp));
+  }
   // exclusive prefix over the block's threads: within the wave by shuffles, across waves through LDS
   uint32_t inc = count;
 #pragma unroll
@@ -725,15 +758,16 @@ __global__ __launch_bounds__(1024) void k_refit_upper(RefitView v, const uint32_
   __syncthreads();
   const uint32_t picked = n_picked;
   uint32_t rounds = 0;
-  bool done = false;
-  float height = 0.f;
-  if (picked > (uint32_t)kTopCap) {
-    if (!last) return;   // too many for this block's LDS: the last launch takes them
+  if (picked > cap) {   // (cap: kTopCap, or less when a test wants to see the paths below)
+    if (!last) {   // too many for this block's LDS: the last launch takes them
+      if (threadIdx.x == 0) atomicOr(&meta[4], 1u);
+      return;
+    }
     // the last launch, with more nodes than LDS holds (tens of millions of primitives): rounds on global memory
     for (uint32_t pass = kTopPassBase;; ++pass) {
       bool progress = false;
       for (uint32_t j = threadIdx.x; j < n_listed; j += 1024u) {
-        const int i = (int)top_list[j];
+        const int i = (int)top_list[j].x;
         if (!(v.stamp[i] & kListedBit)) continue;
         if (try_finish(v, i, pass)) progress = true;
       }
@@ -742,119 +776,124 @@ __global__ __launch_bounds__(1024) void k_refit_upper(RefitView v, const uint32_
     }
   } else if (picked) {
     uint32_t slot = wave_base[wave] + inc - count;
-    for (uint32_t j0 = 0; j0 < n_listed; j0 += 1024u) {
-      const int i = mine(j0 + threadIdx.x);
-      if (i < 0) continue;
-      slot_node[slot] = i;
-      rnd[slot] = 0;
-      ++slot;
+#pragma unroll
+    for (int u = 0; u < kPickE; ++u)
+      if ((first_valid >> u) & 1u) slot_node[slot++] = first_batch[u];
+    for (uint32_t j0 = kPickE * 1024u; j0 < n_listed; j0 += kPickE * 1024u) {
+      int tmp[kPickE];
+      const uint32_t valid = pick_batch(j0, tmp);
+#pragma unroll
+      for (int u = 0; u < kPickE; ++u)
+        if ((valid >> u) & 1u) slot_node[slot++] = tmp[u];
+    }
+    for (uint32_t q = threadIdx.x; q < (uint32_t)kTopCap; q += 1024u) {
+      token[q] = 0u;
+      parent[q] = 0xffffu;
     }
     __syncthreads();
     // (stamps are rewritten only now, after every thread has done its second look at them)
     for (uint32_t q = threadIdx.x; q < picked; q += 1024u) v.stamp[slot_node[q]] = kListedBit | q;
     __syncthreads();
-    int node[kTopE];
-    PendingChild pc[kTopE][2];
-    uint32_t todo = 0;
+    // ---- what each picked node already has: children finished by earlier launches, and leaves
+    Carried ready[kTopE][2];
+    uint32_t n_ready[kTopE];
 #pragma unroll
     for (int k = 0; k < kTopE; ++k) {
       const uint32_t q = (uint32_t)k * 1024u + threadIdx.x;
-      node[k] = -1;
+      n_ready[k] = 0xffu;   // no node
       if (q >= picked) continue;
       const int i = slot_node[q];
-      node[k] = i;
-      todo |= 1u << k;
+      const int under = v.range_count[i];
+      ref_self[q] = (i > 0 && under <= kLeafMaxPrims) ? make_leaf_ref((uint32_t)v.range_first[i], (uint32_t)under) : i;
+      uint32_t have = 0;
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
-        PendingChild &c = pc[k][side];
+        Carried &c = ready[k][side];
         const int cc = side ? v.right[i] : v.left[i];
-        c.wait = -1;
-        c.folded = false;
         float4 lo, hi;
         if (cc < 0) {
           lo = v.leaf_lo[~cc];
           hi = v.leaf_hi[~cc];
           c.ref = lo.w != 0.f ? kNullLeaf : make_leaf_ref((uint32_t)~cc, 1u);
           c.height = 0.f;
+          have |= 1u << side;
         } else {
           const uint32_t st = v.stamp[cc];
-          const int n_under = v.range_count[cc];
-          c.folded = n_under <= kLeafMaxPrims;
-          c.ref = c.folded ? make_leaf_ref((uint32_t)v.range_first[cc], (uint32_t)n_under) : cc;
-          if (st & kListedBit) {   // a child of a picked node that is still listed was picked too
-            c.wait = (int)(st & ~kListedBit);
+          if (st & kListedBit) {   // a child of a picked node that is still listed was picked too: its walk comes by
+            parent[st & ~kListedBit] = (unsigned short)(q | ((uint32_t)side << 15));
             lo = hi = make_float4(0.f, 0.f, 0.f, 0.f);
+            c.ref = 0;
             c.height = 0.f;
           } else {
+            const int n_under = v.range_count[cc];
+            const bool folded = n_under <= kLeafMaxPrims;
+            c.ref = folded ? make_leaf_ref((uint32_t)v.range_first[cc], (uint32_t)n_under) : cc;
             lo = v.box_lo[cc];
             hi = v.box_hi[cc];
-            c.height = c.folded ? 0.f : lo.w;
+            c.height = folded ? 0.f : lo.w;
+            have |= 1u << side;
           }
         }
         c.lo[0] = lo.x; c.lo[1] = lo.y; c.lo[2] = lo.z;
         c.hi[0] = hi.x; c.hi[1] = hi.y; c.hi[2] = hi.z;
       }
+      n_ready[k] = have;
+      if (have == 1u || have == 2u) {   // one child here already: it counts as the first arrival
+        const uint32_t side = have >> 1;
+        if (side) publish_slot(pub, q, ready[k][1]);
+        else publish_slot(pub, q, ready[k][0]);
+        token[q] = (q + 1u) | (side ? kTokenSide : 0u);
+      }
     }
     __syncthreads();
-    for (uint32_t pass = 1;; ++pass) {
-      bool progress = false;
-#pragma unroll
-      for (int k = 0; k < kTopE; ++k) {
-        if (!(todo & (1u << k))) continue;
-        bool ready = true;
-#pragma unroll
-        for (int side = 0; side < 2; ++side)
-          if (pc[k][side].wait >= 0) {
-            const uint32_t r = rnd[pc[k][side].wait];
-            ready = ready && r != 0u && r < pass;
-          }
-        if (!ready) continue;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-          PendingChild &c = pc[k][side];
-          if (c.wait >= 0) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              c.lo[q] = nb[q][c.wait];
-              c.hi[q] = nb[3 + q][c.wait];
-            }
-            c.height = c.folded ? 0.f : nb[6][c.wait];
-          }
-        }
-        const uint32_t q = (uint32_t)k * 1024u + threadIdx.x;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          nb[e][q] = fminf(pc[k][0].lo[e], pc[k][1].lo[e]);
-          nb[3 + e][q] = fmaxf(pc[k][0].hi[e], pc[k][1].hi[e]);
-        }
-        nb[6][q] = fmaxf(pc[k][0].height, pc[k][1].height) + 1.f;
-        rnd[q] = (unsigned short)pass;
-        todo &= ~(1u << k);
-        progress = true;
-      }
-      ++rounds;
-      if (progress) moved[pass % 3u] = 1;
-      if (threadIdx.x == 0) moved[(pass + 1u) % 3u] = 0;
-      __syncthreads();
-      if (!moved[pass % 3u]) break;
-    }
-    // (as in k_refit_local, global memory is written after the rounds: the children are in registers by now)
+    auto node_of = [&](uint32_t q) { return slot_node[q]; };
+    // ---- the nodes with both children here start the walks: there are few of them (one per chain of
+    // nodes along a tile boundary), scattered over the block's threads, so they are gathered first
 #pragma unroll
     for (int k = 0; k < kTopE; ++k) {
-      if (node[k] < 0 || (todo & (1u << k))) continue;
+      if (n_ready[k] != 3u) continue;
+      const uint32_t q = (uint32_t)k * 1024u + threadIdx.x;
+      const int i = slot_node[q];
       float box[7];
-      write_node(v, node[k], pc[k][0], pc[k][1], box);
-      v.box_lo[node[k]] = make_float4(box[0], box[1], box[2], box[6]);
-      v.box_hi[node[k]] = make_float4(box[3], box[4], box[5], 0.f);
-      v.stamp[node[k]] = rnd[(uint32_t)k * 1024u + threadIdx.x];
+      write_record(v, i, ready[k][0], ready[k][1], box);
+      v.box_lo[i] = make_float4(box[0], box[1], box[2], box[6]);
+      v.box_hi[i] = make_float4(box[3], box[4], box[5], 0.f);
+      v.stamp[i] = 1u;
+      if (i == 0) {
+        root_seen[1] = (uint32_t)box[6];
+        root_seen[0] = 1u;
+      }
+      if (parent[q] == 0xffffu) continue;
+      Carried c;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        c.lo[e] = box[e];
+        c.hi[e] = box[3 + e];
+      }
+      c.ref = ref_self[q];
+      c.height = c.ref < 0 ? 0.f : box[6];
+      publish_slot(pub, q, c);
+      queue[atomicAdd(&n_queued, 1u)] = (unsigned short)q;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < n_queued; e += 1024u) {
+      const uint32_t q = queue[e], up = parent[q];
+      uint32_t cur = up & 0x7fffu, side = up >> 15;
+      Carried c = read_slot(pub, q);
+      climb(v, pub, token, parent, ref_self, node_of, q, cur, side, c, true, 0xffffffffu, root_seen);
     }
     __syncthreads();
   }
   if (last && threadIdx.x == 0) {
-    // (no progress with nodes left cannot happen in a tree; the host would see meta[2] == 0)
-    done = v.n_internal > 0 && v.stamp[0] != 0u && !(v.stamp[0] & kListedBit);
-    if (done) height = v.box_lo[0].w;
-    meta[1] = done ? (uint32_t)height : 0u;
+    // the root: finished by this block (LDS says so), or by an earlier launch (its stamp does)
+    bool done = root_seen[0] != 0u;
+    uint32_t height = root_seen[1];
+    if (!done && v.n_internal > 0) {
+      const uint32_t st = v.stamp[0];
+      done = st != 0u && !(st & kListedBit);
+      if (done) height = (uint32_t)v.box_lo[0].w;
+    }
+    meta[1] = done ? height : 0u;
     meta[2] = done ? 1u : 0u;
     meta[3] = rounds;
   }
@@ -889,12 +928,9 @@ hipError_t radix_sort_pairs(uint32_t *const keys[2], uint32_t *const vals[2], ui
   for (int pass = 0; pass < passes; ++pass) {
     const uint32_t shift = 8u * (uint32_t)pass;
     hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(kThreads), 0, stream, keys[cur], n, shift, hist, nblk);
-    const uint32_t n_counters = 256u * nblk, scan_tiles = (n_counters + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(scan_tiles), dim3(kThreads), 0, stream, hist, n_counters, scan_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, scan_sums, scan_tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(scan_tiles), dim3(kThreads), 0, stream, hist, n_counters, scan_sums);
+    hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(kThreads), 0, stream, hist, nblk, scan_sums);
     hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(kThreads), 0, stream, keys[cur], vals[cur], keys[cur ^ 1],
-                       vals[cur ^ 1], n, shift, hist, nblk);
+                       vals[cur ^ 1], n, shift, hist, scan_sums, nblk);
     cur ^= 1;
   }
   return hipGetLastError();
@@ -902,7 +938,7 @@ hipError_t radix_sort_pairs(uint32_t *const keys[2], uint32_t *const vals[2], ui
 void radix_sort_scratch(uint32_t n, size_t *hist_bytes, size_t *sums_bytes) {
   const uint32_t nblk = (n + kRsTile - 1) / kRsTile;
   *hist_bytes = (size_t)256 * nblk * sizeof(uint32_t);
-  *sums_bytes = ((size_t)256 * nblk / kScanTile + 2) * sizeof(uint32_t);
+  *sums_bytes = 256 * sizeof(uint32_t);   // the digit totals of one pass
 }
 
 struct Lbvh::Work {
@@ -913,9 +949,10 @@ struct Lbvh::Work {
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr};
   uint32_t *hist = nullptr, *scan_sums = nullptr, *stamp = nullptr, *cbounds = nullptr;
   int *left = nullptr, *right = nullptr;
-  uint32_t *top_list = nullptr;  // nodes that straddle a tile boundary of k_refit_local
+  uint4 *top_list = nullptr;     // nodes that straddle a tile boundary of k_refit_local, with their runs
   int *range_first = nullptr, *range_count = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint32_t *h_meta = nullptr;    // pinned: the one read-back of a build lands here without a staging copy
   // what the device holds of the host-made inputs (uploads of unchanged content are skipped: a
   // blocking copy per rebuild is a tenth of a small rebuild)
   std::vector<float> up_cr, up_large_geom;
@@ -927,6 +964,7 @@ void Lbvh::release() {
     if (work->slab) hipFree(work->slab);
     if (work->ev0) hipEventDestroy(work->ev0);
     if (work->ev1) hipEventDestroy(work->ev1);
+    if (work->h_meta) hipHostFree(work->h_meta);
     delete work;
     work = nullptr;
   }
@@ -983,6 +1021,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     work = new Work();
     BVH_HIP(hipEventCreate(&work->ev0));
     BVH_HIP(hipEventCreate(&work->ev1));
+    BVH_HIP(hipHostMalloc((void **)&work->h_meta, 8 * sizeof(uint32_t), hipHostMallocDefault));
   }
   const uint32_t nblk = (n + kRsTile - 1) / kRsTile;
   if (n > work->capacity) {
@@ -992,8 +1031,8 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     work->up_cr.clear();  // (lived in the slab)
     const size_t f4 = align256((size_t)n * sizeof(float4)), u4 = align256((size_t)n * sizeof(uint32_t));
     const size_t hist = align256((size_t)256 * nblk * sizeof(uint32_t));
-    const size_t sums = align256(((size_t)256 * nblk / kScanTile + 2) * sizeof(uint32_t));
-    const size_t total = 7 * f4 + 10 * u4 + hist + sums + 512;
+    const size_t sums = align256(256 * sizeof(uint32_t));   // the digit totals of one radix pass
+    const size_t total = 8 * f4 + 9 * u4 + hist + sums + 512;
     BVH_HIP(hipMalloc((void **)&work->slab, total));
     char *p = work->slab;
     auto take = [&](size_t bytes) { char *q = p; p += bytes; return q; };
@@ -1011,7 +1050,7 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     work->stamp = (uint32_t *)take(u4);
     work->left = (int *)take(u4);
     work->right = (int *)take(u4);
-    work->top_list = (uint32_t *)take(u4);
+    work->top_list = (uint4 *)take(f4);
     work->range_first = (int *)take(u4);
     work->range_count = (int *)take(u4);
     work->hist = (uint32_t *)take(hist);
@@ -1114,8 +1153,8 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     BVH_HIP(hipStreamSynchronize(stream));  // cr (pageable host memory) must outlive the copy
     w.up_cr = cr;
   }
-  BVH_HIP(hipMemsetAsync(w.cbounds, 0xff, 3 * sizeof(uint32_t), stream));      // running minima
-  BVH_HIP(hipMemsetAsync(w.cbounds + 3, 0x00, 3 * sizeof(uint32_t), stream));  // running maxima
+  // running minima and maxima of the centres, and the refit's words of meta (one launch instead of three fills)
+  hipLaunchKernelGGL(k_build_init, dim3(1), dim3(128), 0, stream, w.cbounds);
   const uint32_t blocks_n = (n + kThreads - 1) / kThreads;
   hipLaunchKernelGGL(k_leaf_boxes, dim3(std::min(blocks_n, 256u)), dim3(kThreads), 0, stream, w.cr,
                      n_spheres, d_tri, n, bp, w.leaf_lo, w.leaf_hi, w.cbounds);
@@ -1125,15 +1164,10 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
   for (uint32_t shift = 0; shift < 32; shift += 8) {
     hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], n, shift, w.hist,
                        nblk);
-    const uint32_t n_counters = 256u * nblk, scan_tiles = (n_counters + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(scan_tiles), dim3(kThreads), 0, stream, w.hist, n_counters,
-                       w.scan_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, w.scan_sums, scan_tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(scan_tiles), dim3(kThreads), 0, stream, w.hist, n_counters,
-                       w.scan_sums);
+    hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(kThreads), 0, stream, w.hist, nblk, w.scan_sums);
     // the last pass writes the sorted order where the traversal reads it
     hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(kThreads), 0, stream, w.keys[cur], w.vals[cur],
-                       w.keys[cur ^ 1], shift == 24u ? sorted_prim : w.vals[cur ^ 1], n, shift, w.hist, nblk);
+                       w.keys[cur ^ 1], shift == 24u ? sorted_prim : w.vals[cur ^ 1], n, shift, w.hist, w.scan_sums, nblk);
     cur ^= 1;
   }
   // sorted codes in keys[cur], sorted order in sorted_prim
@@ -1145,9 +1179,9 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     const uint32_t blocks_i = (n - 1 + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_hierarchy, dim3(blocks_i), dim3(kThreads), 0, stream, w.keys[cur], (int)n,
                        w.left, w.right, w.range_first, w.range_count);
-    BVH_HIP(hipMemsetAsync(w.stamp, 0, (size_t)(n - 1) * sizeof(uint32_t), stream));
+    // (no stamp is read that this build's first refit launch has not written: the roots of the tiles'
+    // subtrees, the listed nodes, and through them the root of the tree)
     uint32_t *meta = w.cbounds + 64;
-    BVH_HIP(hipMemsetAsync(meta, 0, 256, stream));
     RefitView rv;
     rv.left = w.left; rv.right = w.right;
     rv.range_first = w.range_first; rv.range_count = w.range_count;
@@ -1160,14 +1194,20 @@ int Lbvh::build(const float4 *d_geom, const float *h_spheres64, uint32_t n_spher
     hipLaunchKernelGGL(k_refit_local, dim3(tiles), dim3(kRefitThreads), 0, stream, rv, w.top_list, meta);
     // the nodes that straddle boundaries of those tiles: first the ones inside tiles of 64 x 2048 positions
     // (when there are several such tiles), then, in one block, the rest
-    constexpr uint32_t kMidShift = 17;
+    constexpr uint32_t kMidShift = RT_REFIT_MID_SHIFT;
     const uint32_t mid_tiles = (n + (1u << kMidShift) - 1u) >> kMidShift;
+    // test hook: fewer LDS slots than the kernel has, so that a small scene reaches the paths of a huge one
+    uint32_t top_cap = (uint32_t)kTopCap;
+    if (const char *e = std::getenv("RT_REFIT_TOP_CAP")) top_cap = std::min(top_cap, (uint32_t)std::strtoul(e, nullptr, 10));
     if (mid_tiles > 1u)
-      hipLaunchKernelGGL(k_refit_upper, dim3(mid_tiles), dim3(1024), 0, stream, rv, w.top_list, meta, kMidShift, 0u);
-    hipLaunchKernelGGL(k_refit_upper, dim3(1), dim3(1024), 0, stream, rv, w.top_list, meta, 32u, 1u);
+      hipLaunchKernelGGL(k_refit_upper, dim3(mid_tiles), dim3(1024), 0, stream, rv, w.top_list, meta, kMidShift, 0u, 32u,
+                         top_cap);
+    hipLaunchKernelGGL(k_refit_upper, dim3(1), dim3(1024), 0, stream, rv, w.top_list, meta, 32u, 1u,
+                       mid_tiles > 1u ? kMidShift : 32u, top_cap);
     // ONE look at the device per build: the height sizes the traversal stack of the launches that follow
-    uint32_t h_meta[4] = {0, 0, 0, 0};
-    BVH_HIP(hipMemcpyAsync(h_meta, meta, sizeof h_meta, hipMemcpyDeviceToHost, stream));
+    uint32_t *h_meta = w.h_meta;
+    h_meta[0] = h_meta[1] = h_meta[2] = h_meta[3] = 0u;
+    BVH_HIP(hipMemcpyAsync(h_meta, meta, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     BVH_HIP(hipStreamSynchronize(stream));
     if (h_meta[2] != 1u) {
       if (err) *err = "bounds propagation did not reach the root";

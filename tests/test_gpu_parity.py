@@ -1250,6 +1250,32 @@ def test_lbvh_too_tall_falls_back_to_brute_force_and_says_so(oracle, monkeypatch
     assert want["stats"].bvh_fallback == 0
 
 
+def test_lbvh_refit_paths_of_a_huge_scene_on_a_small_one(oracle, monkeypatch):
+    """The bounds of the nodes that straddle the tiles of the first refit launch are finished by a second
+    launch (tiles of 2^16 positions, above 65,536 primitives) and a last one, each with a few thousand LDS
+    slots per block.  RT_REFIT_TOP_CAP lowers that number: with 40 slots the second launch's blocks leave
+    their nodes to the last one, which then finds them by their stamps and finishes them in rounds on global
+    memory; with 400 the second launch works and the last one runs its rounds.  The tree must come out the
+    same: images, ids and segment counts equal the uncapped build's bit for bit, and the oracle's
+    brute-force render on a pixel sample."""
+    w, h = 128, 96
+    ubo = rt.make_ubo(w, h, 2, 4)
+    sph = rt.grid_spheres_scene(150_000)
+    flags = rt.FLAG_STRICT_MATH | rt.FLAG_FORCE_BVH
+    want = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, flags)
+    assert want["stats"].bvh_nodes == 149_999 and want["stats"].bvh_fallback == 0
+    pix = np.arange(7, w * h, 97, dtype=np.uint32)
+    ref = oracle.render(ubo, sph, w, h, pixels=pix)
+    assert np.array_equal(_bits(want["accum"].reshape(-1, 4)[pix]), _bits(ref["accum"]))
+    assert np.array_equal(want["ids"].reshape(-1)[pix], ref["ids"])
+    for cap in ("40", "400"):
+        monkeypatch.setenv("RT_REFIT_TOP_CAP", cap)
+        got = gpu_render(ubo, sph, w, h, rt.MODE_MEGAKERNEL, flags)
+        assert got["stats"].bvh_height == want["stats"].bvh_height and got["stats"].bvh_fallback == 0
+        assert np.array_equal(_bits(got["accum"]), _bits(want["accum"])) and got["rays"] == want["rays"]
+        assert np.array_equal(got["ids"], want["ids"])
+
+
 def test_replaced_mesh_arrays_do_not_pile_up():
     """rt_set_mesh keeps the outgoing triangle array only for a re-upload of the SAME triangle count; a mesh
     of another size, or a removed mesh, leaves no dead copy behind (48 bytes per triangle)."""
