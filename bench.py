@@ -271,7 +271,7 @@ def main() -> None:
 
     # the accumulation images live in torch tensors so RCCL can reduce them in place
     # configs[3] on one GPU keeps two frames in flight, each in a context and on a stream of its
-    # own: the LBVH rebuild of frame i+1 (sixty small kernels and two host read-backs) then runs
+    # own: the LBVH rebuild of frame i+1 (nineteen small kernels and two host round trips) then runs
     # beside the trace of frame i instead of between two traces.  Every frame is still rebuilt
     # and traced inside the timed region.
     pipelined = world == 1 and ((wl["scene"] == "terrain" and args.images_in_flight != 1) or args.images_in_flight > 1)

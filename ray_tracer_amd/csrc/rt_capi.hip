@@ -210,7 +210,7 @@ int rebuild_accel(rt_ctx *c) {
   if (rc != RT_OK) return fail(rc, "LBVH build: %s", err.c_str());
   std::memcpy(c->bvh_cam, cam, sizeof cam);
   if (std::getenv("RT_BVH_DEBUG"))
-    std::fprintf(stderr, "rt_hip: LBVH over %u primitives: height %u, %u nodes across refit tiles, %u rounds for them\n",
+    std::fprintf(stderr, "rt_hip: LBVH over %u primitives: height %u, %u nodes across refit tiles, %u rounds on global memory\n",
                  n_prims, c->bvh.height, c->bvh.refit_listed, c->bvh.refit_rounds);
   if (c->bvh.height > c->bvh_height_limit) {
     // taller than any launch can give a stack for: trace by brute force (correct, slow) and

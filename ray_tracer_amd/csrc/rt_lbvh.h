@@ -22,8 +22,8 @@ struct Lbvh {
   uint32_t capacity = 0;           // spheres the arrays above can hold
   uint32_t height = 0;             // longest root-to-leaf path in edges = traversal stack bound
   float scene_lo[3] = {0.f, 0.f, 0.f}, scene_hi[3] = {0.f, 0.f, 0.f};  // bounds of sphere centres and mesh vertices
-  uint32_t refit_listed = 0;       // last build: nodes finished by the second refit launch, and its rounds
-  uint32_t refit_rounds = 0;
+  uint32_t refit_listed = 0;       // last build: nodes that straddle the tiles of the first refit launch,
+  uint32_t refit_rounds = 0;       // and the rounds on global memory the last launch needed for them (normally 0)
   float last_build_ms = 0.f;     // use build_ms()
   bool timing_pending = false;
   float build_ms();              // device time of the last build (waits for it if it is still running)

@@ -3,7 +3,7 @@
 //   1. leaf boxes (inflated, see below) + bounds of the centres       k_leaf_boxes
 //   2. 30-bit Morton code of each centre (bits handed to the axes by   k_morton
 //      the shape of the scene)
-//   3. stable LSD radix sort of (code, index), 4 passes of 8 bits     k_rs_hist / k_rs_scan / k_rs_scatter
+//   3. stable LSD radix sort of (code, index), 4 passes of 8 bits     k_rs_hist / k_scan_rows / k_rs_scatter
 //   4. Karras (2012) radix-tree hierarchy over the sorted codes,      k_hierarchy
 //      ties broken by sorted position
 //   5. bottom-up bounds in two or three launches                      k_refit_local / k_refit_upper
@@ -26,19 +26,18 @@
 //
 // Refit without hand-offs between workgroups.  A node of the radix tree covers a contiguous run
 // of sorted positions, and its index is one end of that run.  k_refit_local gives every block a
-// tile of kRefitTile consecutive positions and lets it finish, in rounds separated by workgroup
-// barriers, every node whose run lies inside the tile (its children's runs then do too, so all it
-// reads was written by its own block, and a barrier orders that); the nodes that straddle a tile
-// boundary -- about a dozen per boundary -- go onto a list.  k_refit_upper finishes the listed
-// nodes the same way, first (when there are several) inside tiles of 2^17 positions, one block
-// per tile, then, in ONE block, whatever is left: their children are either listed too and lie in
-// the same tile (same block) or were finished by an earlier launch.  A node is finished in round r
-// only from children finished in a round before r, so it never reads a box that is being written;
-// the rounds run on LDS and registers, global memory is read before them and written after them.
-// No fences, no flags polled across CUs, no dependence on dispatch order or on which XCD a block
-// runs, and ONE look at the device from the host, when the tree is complete (it was 16 launches
-// of a kernel over all nodes and a read-back per round of them: 224 of the 460 microseconds of a
-// million-triangle build; now 140 in three launches, the build 380).
+// tile of kRefitTile consecutive positions and lets it finish every node whose run lies inside the
+// tile (its children's runs then do too, so all it needs comes from its own block): walks climb
+// from the leaves and meet at the nodes through tokens in the block's LDS (see climb).  The nodes
+// that straddle a tile boundary -- about a dozen per boundary -- go onto a list with their runs.
+// k_refit_upper finishes the listed nodes the same way, first (when there are several) inside tiles
+// of 2^RT_REFIT_MID_SHIFT positions, one block per tile, then, in ONE block, whatever is left: their
+// children are either listed too and lie in the same tile (same block) or were finished by an
+// earlier launch.  No fences, no flags polled across CUs, no dependence on dispatch order or on
+// which XCD a block runs, and ONE look at the device from the host, when the tree is complete.
+// (It was 16 launches of a kernel over all nodes and a read-back per round of them: 224 of the 460
+// microseconds of a million-triangle build; then rounds separated by barriers in LDS, 140; the
+// walks take 83, and the build 270.)
 #include "rt_lbvh.h"
 
 #include <algorithm>
@@ -453,9 +452,9 @@ __device__ __forceinline__ void finish_node(const RefitView &v, int i, int c0, i
 constexpr int kRefitTile = 2048;                     // sorted positions (and node indices) per block of k_refit_local
 constexpr int kRefitThreads = 1024;
 constexpr int kRefitE = kRefitTile / kRefitThreads;  // nodes per thread
-constexpr int kTopCap = 3072;                        // listed nodes k_refit_top keeps in LDS (more: its slow path)
+constexpr int kTopCap = 3072;                        // listed nodes a block of k_refit_upper has LDS slots for
 constexpr int kTopE = kTopCap / 1024;
-constexpr uint32_t kTopPassBase = 0x01000000u;       // slow path: its rounds are numbered from here (above any local round)
+constexpr uint32_t kTopPassBase = 0x01000000u;       // the last launch's rounds on global memory are numbered from here (above the stamp of a finished node)
 constexpr uint32_t kListedBit = 0x80000000u;         // stamp of a listed node until it is finished: this bit | its slot
 
 // ---- bounds, bottom-up, without rounds -------------------------------------------------------
@@ -661,7 +660,7 @@ __global__ __launch_bounds__(kRefitThreads) void k_refit_local(RefitView v, uint
     }
 }
 
-// slow path of k_refit_top: one attempt at node i in round `pass` on global memory
+// k_refit_upper's last launch with more nodes than slots: one attempt at node i in round `pass` on global memory
 __device__ __forceinline__ bool try_finish(const RefitView &v, int i, uint32_t pass) {
   int c0 = v.left[i], c1 = v.right[i];
   if (!child_ready(v, c0, pass) || !child_ready(v, c1, pass)) return false;
@@ -673,13 +672,13 @@ __device__ __forceinline__ bool try_finish(const RefitView &v, int i, uint32_t p
   return true;
 }
 
-// The listed nodes, level by level.  A launch with tile_shift = t finishes every listed node whose run of
-// sorted positions lies inside one tile of 2^t positions (block b takes tile b); the last launch, one
-// block with t = 32, takes whatever is left.  A block picks its nodes off the list, gives them LDS slots
-// (the stamp of a picked node becomes kListedBit | its slot, which is how a parent finds a child that
-// the same block finishes), fetches the boxes of children that an earlier launch finished, and then
-// runs the rounds on registers and LDS alone.  A block that finds more nodes than it has slots leaves
-// them to the last launch, which falls back to rounds on global memory when it, too, has too many.
+// The listed nodes.  A launch with tile_shift = t finishes every listed node whose run of sorted
+// positions lies inside one tile of 2^t positions (block b takes tile b); the last launch, one block,
+// takes whatever is left.  A block picks its nodes off the list, gives them LDS slots (the stamp of a
+// picked node becomes kListedBit | its slot, which is how a parent finds a child that the same block
+// finishes), fetches the boxes of children that an earlier launch finished, and lets walks climb from
+// the nodes that have both children (see climb).  A block that finds more nodes than it has slots
+// leaves them to the last launch, which falls back to rounds on global memory when it, too, has too many.
 __global__ __launch_bounds__(1024) void k_refit_upper(RefitView v, const uint4 *__restrict__ top_list,
                                                       uint32_t *meta, uint32_t tile_shift, uint32_t last,
                                                       uint32_t earlier_shift, uint32_t cap) {

@@ -90,29 +90,53 @@ __global__ __launch_bounds__(256) void k_expand_triangles(const float *__restric
   float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   uint32_t bad = 0xffffffffu;
-  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tris; t += gridDim.x * 256u) {
-    float c[3][3];
+  // kExpandE triangles per thread and iteration, the loads of one kind issued together: the grid is kept
+  // small for the atomics below, so a thread must have several gathers in flight (one triangle at a
+  // time, the million-triangle terrain took 35 us, two dependent round trips per iteration)
+  constexpr int kExpandE = 4;
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t t0 = blockIdx.x * 256u + threadIdx.x; t0 < n_tris; t0 += stride * kExpandE) {
+    uint32_t idx[kExpandE][3];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      uint32_t idx = indices[3u * t + v];
-      if (idx >= n_vertices) {
-        bad = bad < 3u * t + v ? bad : 3u * t + v;
-        idx = 0;
-      }
-      const float *p = vertices + 3u * (size_t)idx;
-      c[v][0] = p[0]; c[v][1] = p[1]; c[v][2] = p[2];
-      mn[0] = fminf(mn[0], c[v][0]); mn[1] = fminf(mn[1], c[v][1]); mn[2] = fminf(mn[2], c[v][2]);
-      mx[0] = fmaxf(mx[0], c[v][0]); mx[1] = fmaxf(mx[1], c[v][1]); mx[2] = fmaxf(mx[2], c[v][2]);
+    for (int u = 0; u < kExpandE; ++u) {
+      const uint32_t t = t0 + (uint32_t)u * stride;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) idx[u][v] = t < n_tris ? indices[3u * t + v] : 0u;
     }
-    const float e1[3] = {c[1][0] - c[0][0], c[1][1] - c[0][1], c[1][2] - c[0][2]};
-    const float e2[3] = {c[2][0] - c[0][0], c[2][1] - c[0][1], c[2][2] - c[0][2]};
-    const float nx = __builtin_fmaf(e1[1], e2[2], -(e1[2] * e2[1])), ny = __builtin_fmaf(e1[2], e2[0], -(e1[0] * e2[2])),
-                nz = __builtin_fmaf(e1[0], e2[1], -(e1[1] * e2[0]));
-    const bool flat = nx == 0.0f && ny == 0.0f && nz == 0.0f;
+    float c[kExpandE][3][3];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const int s = flat ? 0 : v;
-      tri[3u * t + v] = make_float4(c[s][0], c[s][1], c[s][2], 0.f);
+    for (int u = 0; u < kExpandE; ++u) {
+      const uint32_t t = t0 + (uint32_t)u * stride;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        uint32_t i = idx[u][v];
+        if (i >= n_vertices) {
+          if (t < n_tris) bad = bad < 3u * t + v ? bad : 3u * t + v;
+          i = 0;
+        }
+        const float *p = vertices + 3u * (size_t)i;
+        c[u][v][0] = p[0]; c[u][v][1] = p[1]; c[u][v][2] = p[2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kExpandE; ++u) {
+      const uint32_t t = t0 + (uint32_t)u * stride;
+      if (t >= n_tris) continue;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        mn[0] = fminf(mn[0], c[u][v][0]); mn[1] = fminf(mn[1], c[u][v][1]); mn[2] = fminf(mn[2], c[u][v][2]);
+        mx[0] = fmaxf(mx[0], c[u][v][0]); mx[1] = fmaxf(mx[1], c[u][v][1]); mx[2] = fmaxf(mx[2], c[u][v][2]);
+      }
+      const float e1[3] = {c[u][1][0] - c[u][0][0], c[u][1][1] - c[u][0][1], c[u][1][2] - c[u][0][2]};
+      const float e2[3] = {c[u][2][0] - c[u][0][0], c[u][2][1] - c[u][0][1], c[u][2][2] - c[u][0][2]};
+      const float nx = __builtin_fmaf(e1[1], e2[2], -(e1[2] * e2[1])), ny = __builtin_fmaf(e1[2], e2[0], -(e1[0] * e2[2])),
+                  nz = __builtin_fmaf(e1[0], e2[1], -(e1[1] * e2[0]));
+      const bool flat = nx == 0.0f && ny == 0.0f && nz == 0.0f;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const int s = flat ? 0 : v;
+        tri[3u * t + v] = make_float4(c[u][s][0], c[u][s][1], c[u][s][2], 0.f);
+      }
     }
   }
   // wave, then block, then one atomic per block and value
@@ -160,7 +184,7 @@ hipError_t launch_expand_triangles(const float *vertices, uint32_t n_vertices, c
   if (e == hipSuccess) e = hipMemsetAsync(report + 4, 0x00, 3 * sizeof(uint32_t), stream);  // maxima
   if (e != hipSuccess) return e;
   uint32_t blocks = (n_tris + 255u) / 256u;
-  if (blocks > 256u) blocks = 256u;
+  if (blocks > 512u) blocks = 512u;
   hipLaunchKernelGGL(k_expand_triangles, dim3(blocks), dim3(256), 0, stream, vertices, n_vertices, indices,
                      n_tris, tri, report);
   return hipGetLastError();
