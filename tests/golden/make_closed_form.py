@@ -423,6 +423,35 @@ def case_exact_ties():
     return c
 
 
+def case_mirror_image_ties():
+    """The same strict < between DIFFERENT spheres: two balls that are mirror images of each other in the
+    plane x = 0, seen along rays that lie in that plane (the pixel column x = 400 of the 800-wide window:
+    ndc.x = 2 * 400 / 800 - 1 = 0, so the direction's x is exactly 0).  x enters a ray's quadratic only
+    as oc.x * d.x = +-0 and oc.x^2, so both balls give the same distance bit for bit in any evaluation,
+    and the lower index must win: pair one lists the ball at +x first, pair two the ball at -x."""
+    ubo = make_ubo(800, 600, 1, 1, ground=(0, 0, 0), horizon=(0, 0, 0), zenith=(0, 0, 0))
+    geo = [((0.6, 2.2, -5), 1), ((-0.6, 2.2, -5), 1), ((-0.7, -2.0, -6), 1.25), ((0.7, -2.0, -6), 1.25)]
+    digits = [(10, 20, 30), (200, 100, 50), (77, 3, 250), (9, 99, 199)]
+    full = np.stack([sphere(p, r, (0.5, 0.5, 0.5), emission=[(v / 255.0) ** 2 for v in dg], strength=1.0)
+                     for (p, r), dg in zip(geo, digits)])
+    first = [0, 2]                                             # the lower index of each pair
+    pix = [(400, y) for y in range(608)]
+    assert all(primary_direction(x, y, ubo)[0] == 0.0 for x, y in pix)
+    c = deterministic_case("mirror_image_ties_lowest_index", "172-190", case_mirror_image_ties.__doc__, ubo,
+                           full[first], 800, 608, pix, tol=BASE_TOL)
+    twin = deterministic_case("twin", "", "", ubo, full[[1, 3]], 800, 608, pix, tol=BASE_TOL)
+    assert [r["rgb"] == [0, 0, 0] for r in c["pixels"]] == [r["rgb"] == [0, 0, 0] for r in twin["pixels"]]
+    seen = set()
+    for r in c["pixels"]:
+        if r["id"] >= 0:
+            r["id"] = first[r["id"]]
+            assert r["rgba8"] == list(digits[r["id"]]) + [255], r
+            seen.add(r["id"])
+    assert seen == {0, 2}, seen
+    c["spheres"] = [[float(v) for v in sp] for sp in full]
+    return c
+
+
 def case_constant_radiance():
     """ground = horizon = zenith = c makes the environment the constant c; a lone convex sphere cannot
     be hit twice (near root only, scattered directions point outwards), so EVERY path through an
@@ -752,7 +781,7 @@ def case_statistical():
 
 def main():
     cases = [case_environment(), case_environment_rotated(), case_default_scene_sky(), case_mirror(),
-             case_mirror_chain(), case_emission_order(), case_emission_digits(), case_exact_ties()]
+             case_mirror_chain(), case_emission_order(), case_emission_digits(), case_exact_ties(), case_mirror_image_ties()]
     cases += case_constant_radiance()
     cases += [case_replay_lone_sphere(), case_replay_default_scene()]
     cases.append(case_blend())
