@@ -94,6 +94,11 @@ struct rt_ctx {
   float mesh_material[12] = {0};
 
   uint32_t *d_mesh_report = nullptr;  // 7 words an upload's device checks report in (kept between uploads)
+  uint32_t *h_mesh_report = nullptr;  // where they are read back to (pinned: no staging copy on the way)
+  // the mesh's material record as the device holds it (slot = the sphere count it was written behind):
+  // an upload that changes neither skips the blocking 48-byte copy
+  float mesh_material_dev[12] = {0};
+  int64_t mesh_material_slot = -1;
   float *d_ior = nullptr;        // per sphere, > 0: dielectric (optional; null: none)
   bool have_ior = false;
 
@@ -321,6 +326,7 @@ int rt_destroy(rt_ctx *c) {
   if (c->d_tri_spare) hipFree(c->d_tri_spare);
   if (c->d_ior) hipFree(c->d_ior);
   if (c->d_mesh_report) hipFree(c->d_mesh_report);
+  if (c->h_mesh_report) hipHostFree(c->h_mesh_report);
   if (c->d_texels) hipFree(c->d_texels);
   if (c->d_tex_lut) hipFree(c->d_tex_lut);
   if (c->d_tex) hipFree(c->d_tex);
@@ -422,6 +428,7 @@ static int rt_set_spheres_impl(rt_ctx *c, const void *spheres64, uint32_t count)
   c->d_geom = nullptr;
   if (c->d_material) RT_HIP(hipFree(c->d_material));
   c->d_material = nullptr;
+  c->mesh_material_slot = -1;
   // the brute-force search fetches geometry four records at a time: pad, and clear the padding
   const size_t alloc_n = ((size_t)count + 3u) / 4u * 4u + 4u;
   RT_HIP(hipMalloc(&c->d_geom, alloc_n * sizeof(float4)));
@@ -429,6 +436,8 @@ static int rt_set_spheres_impl(rt_ctx *c, const void *spheres64, uint32_t count)
   RT_HIP(hipMalloc(&c->d_material, ((size_t)count + 1) * 3 * sizeof(float4)));  // + the mesh's
   RT_HIP(hipMemcpy(c->d_material + 3 * (size_t)count, c->mesh_material, sizeof c->mesh_material,
                    hipMemcpyHostToDevice));
+  std::memcpy(c->mesh_material_dev, c->mesh_material, sizeof c->mesh_material);
+  c->mesh_material_slot = (int64_t)count;
   c->h_spheres.assign((const float *)spheres64, (const float *)spheres64 + (size_t)count * 16);
   if (count) {
     // repack the 64-byte records: geometry (centre, r*r) apart from the material,
@@ -466,7 +475,13 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
   if (n_triangles > (1u << 26)) return fail(RT_ERR_INVALID, "rt_set_mesh: %u triangles", n_triangles);
   if (n_triangles && n_vertices == 0) return fail(RT_ERR_INVALID, "rt_set_mesh: triangles without vertices");
   RT_HIP(hipSetDevice(c->device));
-  RT_HIP(hipStreamSynchronize(c->stream));
+  // A mesh re-uploaded every frame from device memory into the spare array of its size touches nothing a
+  // launch in flight reads (the spare was last read before the previous upload, which waited for its own
+  // report), and everything it enqueues is ordered behind those launches on the context's stream: no need
+  // to drain the stream first.  Every other case may allocate, free or overwrite what is in use.
+  const bool in_place = on_device && n_triangles && c->d_tri_spare && c->tri_spare_n == n_triangles &&
+                        c->d_mesh_report && c->h_mesh_report;
+  if (!in_place) RT_HIP(hipStreamSynchronize(c->stream));
 
   // The new mesh is expanded, checked and measured on the device BEFORE the old one is
   // dropped, so a rejected upload (index out of range) leaves the context as it was.
@@ -475,10 +490,12 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
   if (n_triangles) {
     float *d_v = nullptr;
     uint32_t *d_i = nullptr;
-    uint32_t report[7];
     // (no allocation or release per upload where it can be helped: hipFree waits for the device)
-    hipError_t e = c->d_mesh_report ? hipSuccess : hipMalloc(&c->d_mesh_report, sizeof report);
+    hipError_t e = c->d_mesh_report ? hipSuccess : hipMalloc(&c->d_mesh_report, 7 * sizeof(uint32_t));
+    if (e == hipSuccess && !c->h_mesh_report)
+      e = hipHostMalloc((void **)&c->h_mesh_report, 8 * sizeof(uint32_t), hipHostMallocDefault);
     uint32_t *d_report = c->d_mesh_report;
+    uint32_t *report = c->h_mesh_report;
     // the triangle array of the previous mesh is reused when the new one has as many triangles
     // and a spare exists (a mesh re-uploaded every frame then allocates nothing here)
     if (e == hipSuccess) {
@@ -503,7 +520,7 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
     }
     if (e == hipSuccess)
       e = rt::launch_expand_triangles(d_v, n_vertices, d_i, n_triangles, new_tri, d_report, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(report, d_report, sizeof report, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(report, d_report, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     uint32_t bad_index = 0;
     if (e == hipSuccess && report[0] != 0xffffffffu) {
@@ -565,10 +582,17 @@ static int set_mesh(rt_ctx *c, const float *vertices, uint32_t n_vertices, const
     RT_HIP(hipMalloc(&c->d_geom, 4 * sizeof(float4)));
     RT_HIP(hipMemset(c->d_geom, 0, 4 * sizeof(float4)));
     RT_HIP(hipMalloc(&c->d_material, 3 * sizeof(float4)));
+    c->mesh_material_slot = -1;
     c->n_spheres = 0;
   }
-  RT_HIP(hipMemcpy(c->d_material + 3 * (size_t)c->n_spheres, c->mesh_material, sizeof c->mesh_material,
-                   hipMemcpyHostToDevice));
+  if (c->mesh_material_slot != (int64_t)c->n_spheres ||
+      std::memcmp(c->mesh_material_dev, c->mesh_material, sizeof c->mesh_material) != 0) {
+    c->mesh_material_slot = -1;
+    RT_HIP(hipMemcpy(c->d_material + 3 * (size_t)c->n_spheres, c->mesh_material, sizeof c->mesh_material,
+                     hipMemcpyHostToDevice));
+    std::memcpy(c->mesh_material_dev, c->mesh_material, sizeof c->mesh_material);
+    c->mesh_material_slot = (int64_t)c->n_spheres;
+  }
   int rc = rebuild_accel(c);
   if (rc != RT_OK) return rc;
   c->have_scene = true;
