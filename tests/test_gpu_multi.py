@@ -1,7 +1,7 @@
 """The N > 1 path with the HIP kernels, on however many devices the box has.
 
-On a one-GPU box: two processes share device 0, each traces its share of the frames with the
-kernels, the sum goes through gloo on host copies.  On a multi-GPU box the same tests also run with
+On a one-GPU box: two (and eight) processes share device 0, each traces its share of the frames with
+the kernels, the sum goes through gloo on host copies.  On a multi-GPU box the same tests also run with
 one device per rank and RCCL (2, 4, 8 ranks up to the device count), `rt_headless --gpus N` sums
 with ncclReduce between N devices of one process, and `bench.py --gpus N` prints its line.
 The partition is the shader's own: frames are independent sample batches (ray_tracing.comp:80-82)
@@ -58,9 +58,10 @@ def _single(strict):
 
 
 def _ranks():
-    """2 ranks always (sharing device 0 when the box has one GPU); 4 and 8 when there are that many devices."""
+    """2 and 8 ranks always (sharing device 0 through gloo when the box has fewer devices: the smallest
+    and the largest run, one frame per rank at 8); 4 when there are that many devices."""
     n = _device_count()
-    return [2] + [k for k in (4, 8) if k <= n]
+    return [2, 8] + ([4] if 4 <= n else [])
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -135,15 +136,15 @@ def test_headless_driver_reports_a_failing_rank_instead_of_hanging():
 
 @pytest.mark.parametrize("gpus", [2, 4, 8])
 def test_bench_line_on_n_devices(gpus):
-    """bench.py --gpus N as the driver launches it (RCCL).  On a one-GPU box the N = 2 control flow is
-    rehearsed with both ranks on device 0 and gloo on host copies -- not a measurement."""
+    """bench.py --gpus N as the driver launches it (RCCL).  On a one-GPU box the control flow of N = 2 and
+    N = 8 is rehearsed with all ranks on device 0 and gloo on host copies -- not a measurement."""
     n_dev = _device_count()
     args = [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--config", "0",
             "--no-side-runs"]
     if gpus > n_dev:
-        if gpus != 2:
+        if gpus == 4:
             pytest.skip(f"--gpus {gpus} needs {gpus} devices, the box has {n_dev}")
-        args += ["--backend", "gloo", "--rehearse-on-device", "0"]
+        args += ["--backend", "gloo", "--rehearse-on-device", "0"]   # (2 and 8 ranks: the driver's smallest and largest run)
     res = _torchrun(gpus, args)
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
