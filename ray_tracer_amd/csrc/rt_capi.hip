@@ -129,6 +129,12 @@ struct rt_ctx {
   // the order is refreshed after launches 1, 2, 4, 8, then every 16th since the last change
   // of scene or parameters; in between the costs keep accumulating (atomicMax)
   uint32_t order_interval = 1, launches_since_order = 0;
+  // The refresh of the order after a launch runs on a stream of its own, tied to the context's by two
+  // events: it needs the launch's costs and the NEXT launch needs its order, but nothing else queued in
+  // between (an upload, an LBVH rebuild) has to wait for it.
+  hipStream_t order_stream = nullptr;
+  hipEvent_t order_in = nullptr, order_out = nullptr;
+  bool order_pending = false;
 
   // HIP event pairs around each rt_render; resolved lazily so rendering never waits
   struct EventPair {
@@ -314,6 +320,12 @@ int rt_destroy(rt_ctx *c) {
   if (!c) return RT_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->order_stream) {
+    hipStreamSynchronize(c->order_stream);
+    hipStreamDestroy(c->order_stream);
+  }
+  if (c->order_in) hipEventDestroy(c->order_in);
+  if (c->order_out) hipEventDestroy(c->order_out);
   if (c->own_accum && c->d_accum) hipFree(c->d_accum);
   if (c->d_rgba8) hipFree(c->d_rgba8);
   if (c->d_ids) hipFree(c->d_ids);
@@ -713,7 +725,12 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
   const bool strict = (c->flags & RT_FLAG_STRICT_MATH) != 0;
   const bool degenerate = c->P.n_spp < 1 || c->P.n_bounce < 1;
 
-  hipError_t he = hipEventRecord(ev.begin, c->stream);
+  hipError_t he = hipSuccess;
+  if (c->order_pending) {   // the order this launch runs in (and the cleared costs it adds to) must be there
+    he = hipStreamWaitEvent(c->stream, c->order_out, 0);
+    c->order_pending = false;
+  }
+  if (he == hipSuccess) he = hipEventRecord(ev.begin, c->stream);
   uint32_t launches = 0;
   int rc = RT_OK;
   bool ordered = false;
@@ -763,11 +780,26 @@ static int rt_render_impl(rt_ctx *c, uint32_t first_frame, uint32_t n_frames, ui
   }
   if (he == hipSuccess && rc == RT_OK) he = hipEventRecord(ev.end, c->stream);
   if (he == hipSuccess && rc == RT_OK && ordered && ++c->launches_since_order >= c->order_interval) {
-    // what the launches since the last refresh measured becomes the next launch's order
-    // (outside the timed pair)
-    he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, c->stream,
-                               c->d_tile_order + c->n_tiles, c->tiles_x);
+    // what the launches since the last refresh measured becomes the next launch's order (outside the
+    // timed pair).  While every launch refreshes it -- the scene or the view has just changed, e.g. a
+    // mesh re-uploaded per frame -- the refresh runs beside whatever the caller queues before the next
+    // launch; a settled view refreshes every 16th launch, in line (four stream calls cost more there).
+    const bool beside = c->order_interval == 1u;
+    if (beside && !c->order_stream) {
+      he = hipStreamCreateWithFlags(&c->order_stream, hipStreamNonBlocking);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&c->order_in, hipEventDisableTiming);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&c->order_out, hipEventDisableTiming);
+    }
+    if (beside) {
+      if (he == hipSuccess) he = hipEventRecord(c->order_in, c->stream);
+      if (he == hipSuccess) he = hipStreamWaitEvent(c->order_stream, c->order_in, 0);
+    }
+    if (he == hipSuccess)
+      he = rt::launch_tile_order(c->d_tile_cost, c->d_tile_order, c->n_tiles, beside ? c->order_stream : c->stream,
+                                 c->d_tile_order + c->n_tiles, c->tiles_x);
+    if (beside && he == hipSuccess) he = hipEventRecord(c->order_out, c->order_stream);
     if (he == hipSuccess) {
+      c->order_pending = beside;
       c->order_valid = true;
       c->order_moved = false;
     }
@@ -789,6 +821,7 @@ int rt_sync(rt_ctx *c) {
   if (!c) return fail(RT_ERR_INVALID, "rt_sync: null context");
   RT_HIP(hipSetDevice(c->device));
   RT_HIP(hipStreamSynchronize(c->stream));
+  if (c->order_pending) RT_HIP(hipStreamSynchronize(c->order_stream));
   return RT_OK;
 }
 
