@@ -124,8 +124,11 @@ int rt_set_mesh(rt_ctx *ctx, const float *vertices, uint32_t n_vertices, const u
 
 /* The same with vertices and indices already resident in device memory (same layouts), for a
  * mesh that another kernel animates every frame: nothing crosses the host-device link.  The
- * arrays are read during the call, which returns after the acceleration structure is rebuilt;
- * material is host memory. */
+ * arrays are read during the call, by kernels on the context's stream (whatever writes them must be
+ * ordered before it: the same stream, or an event), and the call returns after the acceleration
+ * structure is rebuilt; material is host memory.  A mesh re-uploaded with the triangle count of the
+ * one before it costs two host round trips (validity and bounds of the upload; height of the
+ * tree) and does not wait for launches already queued on the stream. */
 int rt_set_mesh_device(rt_ctx *ctx, const float *d_vertices, uint32_t n_vertices,
                        const uint32_t *d_indices, uint32_t n_triangles, const rt_material *material);
 
